@@ -1,0 +1,160 @@
+/* mpcq.h — C ABI of libmpcq.so, the MI355X (gfx950) batched MPC+RGP control-step engine.
+ *
+ * Drop-in boundary.  In the reference the hot path sits behind the Python class
+ * `quad_optimizer` (src/quad_opt.py:35) whose only native FFI is acados_template's ctypes binding
+ * of the generated solver: `.set(stage,'yref'|'lbx'|'ubx'|'p',…)`, `.solve()`, `.get(stage,'x'|'u')`,
+ * `.get_stats('time_tot')`, `.get_cost()` (src/quad_opt.py:286-290,311-315,328-333,342-350,404),
+ * plus numpy code for the recursive GP (src/gp/RGP.py:303-330 through src/gp/GPE.py:244-268).
+ * This header is the batched analogue: one engine = B independent quadrotors advanced in lockstep,
+ * all state (SQP iterate, RGP mean/covariance, trajectory cursor) resident in HBM between calls.
+ *
+ * Conventions: every function returns 0 on success and a negative mpcq_status on failure
+ * (mpcq_last_error() gives the message).  All host arrays are caller-owned, C-contiguous,
+ * float64, batch-major [B, ...] exactly like the numpy arrays of the reference facade; the
+ * engine converts to its compute precision on the device.  Calls block until the result is
+ * available unless the name ends in _async.  Not thread-safe per handle (the reference drives
+ * its solver from one rospy callback thread, src/mpc_controller_node.py:234).
+ *
+ * State layout: x = [p(3), q = (w,x,y,z)(4), v(3) world, r(3) body]  (src/quad_opt.py:168-174),
+ * u in [0,1]^4 (src/quad_opt.py:142-144), y = [x, u] (17).
+ */
+#ifndef MPCQ_H
+#define MPCQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCQ_NX 13
+#define MPCQ_NU 4
+#define MPCQ_NY 17
+
+typedef enum mpcq_status {
+  MPCQ_OK = 0,
+  MPCQ_ERR_INVALID = -1,   /* bad argument / configuration */
+  MPCQ_ERR_DEVICE = -2,    /* HIP runtime error (no GPU, OOM, launch failure) */
+  MPCQ_ERR_STATE = -3,     /* call sequence error (e.g. step before set_trajectories) */
+  MPCQ_ERR_COMM = -4       /* RCCL error */
+} mpcq_status;
+
+/* per-instance solver status, the acados return codes the reference discards (src/quad_opt.py:333) */
+#define MPCQ_SOLVE_OK 0
+#define MPCQ_SOLVE_NAN 1
+#define MPCQ_SOLVE_MAXITER 2
+#define MPCQ_SOLVE_QP_FAILURE 4
+
+#define MPCQ_PRECISION_F64 0
+#define MPCQ_PRECISION_F32 1
+
+/* Engine configuration.  Replaces the constructor arguments of quad_optimizer
+ * (quad, t_horizon, n_nodes, gpe; src/quad_opt.py:36) and the constants it bakes into the
+ * generated solver (weights src/quad_opt.py:122-130, bounds :142-144, quad constants
+ * src/quad.py:385-417, RGP basis/theta src/gp/RGP.py:126-157). */
+typedef struct mpcq_config {
+  int32_t batch;      /* B: number of independent quadrotors in this engine (this rank's shard) */
+  int32_t N;          /* n_nodes: shooting intervals */
+  int32_t nb;         /* RGP basis points per axis (0: nominal model, use_gp=0) */
+  int32_t skip;       /* control_freq_factor = int(optimization_dt / 0.01), src/mpc_controller_node.py:222 */
+  double T;           /* t_horizon [s] */
+  double dt_pred;     /* step of the nominal prediction: ODOMETRY_DT 0.01 (node) or T/N (python sim) */
+  double mass, J[3], max_thrust, x_f[4], y_f[4], z_l_tau[4], g;
+  double rotor_drag[3], aero_drag; /* plant only (src/quad.py:79-89); unused by the controller path */
+  double W[17], W_e[13];           /* diagonal LS weights; stage cost is scaled by T/N (acados) */
+  double u_lb[4], u_ub[4], u_ref[4];
+  double qp_tol;      /* KKT tolerance of the box-QP solve; 0 = default for the precision */
+  const double* basis;   /* [3*nb] basis vectors X per axis */
+  const double* theta;   /* [3*3] per axis: L, sigma_f, sigma_n */
+  int32_t device;        /* HIP device ordinal */
+  int32_t precision;     /* MPCQ_PRECISION_* : arithmetic type of the device path */
+  int32_t qp_max_iter;   /* 0 = default */
+  int32_t reserved;
+} mpcq_config;
+
+typedef struct mpcq_engine mpcq_engine;
+
+const char* mpcq_last_error(void);
+const char* mpcq_version(void);
+
+/* ---- lifetime.  quad_optimizer.__init__ (src/quad_opt.py:36-160): builds constants, K_x^-1,
+ * allocates device state and zero-initialises the iterate (acados default), mu=0, C=K_x. */
+int mpcq_create(const mpcq_config* cfg, mpcq_engine** out);
+int mpcq_destroy(mpcq_engine* e);
+int mpcq_reset(mpcq_engine* e);
+
+/* ---- reference.  Fused path: whole sampled trajectories stay on the device and the kernel
+ * performs get_reference_chunk (src/utils/utils.py:897-931) + set_reference_trajectory
+ * (src/quad_opt.py:295-317) itself.  traj [B, Tmax, 13], len [B] (rows valid per instance);
+ * resets the trajectory cursor idx_traj to 0 (src/mpc_controller_node.py:517-552). */
+int mpcq_set_trajectories(mpcq_engine* e, const double* traj, const int32_t* len, int32_t Tmax);
+/* Explicit path: acados .set(j,'yref',·) for j<N and .set(N,'yref',·)  (src/quad_opt.py:311,315).
+ * yref [B, N, 17], yrefN [B, 13]. */
+int mpcq_set_reference(mpcq_engine* e, const double* yref, const double* yrefN);
+/* acados .set(ii,'p',rgp_params) on every stage (src/quad_opt.py:402-404). mu [B, 3*nb] */
+int mpcq_set_params(mpcq_engine* e, const double* mu);
+
+/* ---- quad_optimizer.run_optimization (src/quad_opt.py:321-350): pin x0, ONE SQP-RTI iteration
+ * on the persisted iterate, using the stored reference and parameters.  x0 [B, 13]. */
+int mpcq_solve(mpcq_engine* e, const double* x0);
+int mpcq_get_x(mpcq_engine* e, int32_t stage, double* out);      /* .get(stage,'x') -> [B,13] */
+int mpcq_get_u(mpcq_engine* e, int32_t stage, double* out);      /* .get(stage,'u') -> [B,4]  */
+int mpcq_get_cost(mpcq_engine* e, double* out);                  /* .get_cost()     -> [B]    */
+int mpcq_get_status(mpcq_engine* e, int32_t* out);               /* solve() status  -> [B]    */
+int mpcq_get_qp_iter(mpcq_engine* e, int32_t* out);              /* IPM iterations  -> [B]    */
+/* .get_stats('time_tot'): device time of the last solve/step launch in seconds (whole batch) */
+int mpcq_get_stats(mpcq_engine* e, double* time_tot);
+
+/* ---- quad_optimizer.discrete_dynamics on the nominal model (src/quad_opt.py:353-377,
+ * src/mpc_controller_node.py:298).  x [B,13], u [B,4] -> out [B,13] */
+int mpcq_predict_nominal(mpcq_engine* e, const double* x, const double* u, double dt, double* out);
+
+/* ---- quad_optimizer.regress_and_update_RGP_model (src/quad_opt.py:380-406): 3 scalar RGP
+ * Kalman updates per instance and the new means become the stage parameters.
+ * v_body [B,3], a_drag [B,3]. */
+int mpcq_rgp_regress(mpcq_engine* e, const double* v_body, const double* a_drag);
+int mpcq_get_rgp(mpcq_engine* e, double* mu /*[B,3,nb] or NULL*/, double* C /*[B,3,nb,nb] or NULL*/);
+
+/* ---- fused control step = the loop body src/mpc_controller_node.py:278-318
+ * (src/execute_trajectory.py:202-258): chunk -> yref -> solve -> w=U[0] -> nominal prediction ->
+ * idx_traj++ -> compute_a_drag -> RGP regress -> params.  x_meas [B,13] -> w_out [B,4];
+ * x_pred_out [B,13] may be NULL. */
+int mpcq_step(mpcq_engine* e, const double* x_meas, double* w_out, double* x_pred_out);
+/* Same with device-resident buffers in the engine's compute precision (float for F32, double for
+ * F64): no host traffic, no synchronisation; ordered on the engine's stream. */
+int mpcq_step_device_async(mpcq_engine* e, const void* d_x_meas, void* d_w_out);
+int mpcq_synchronize(mpcq_engine* e);
+void* mpcq_stream(mpcq_engine* e);   /* hipStream_t the engine launches on */
+
+/* ---- closed-loop harness on the device: Quadrotor3D.update with drag
+ * (src/quad.py:166-190,234-277,329-357) applied n_sub times with step sim_dt to the engine's
+ * internal plant state, driven by the last w.  mpcq_sim_reset sets the plant state [B,13];
+ * mpcq_sim_steps runs K closed-loop iterations {step(x) -> plant} without host round trips. */
+int mpcq_sim_reset(mpcq_engine* e, const double* x0);
+int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt);
+int mpcq_sim_get_state(mpcq_engine* e, double* x /*[B,13]*/, double* w /*[B,4] or NULL*/);
+
+/* ---- tracking statistic (src/Visualiser.py:787-789,809-811,918), summed over this engine's
+ * instances since the last reset: out[0]=sum |e_pos|^2, out[1]=sum |e_vel|^2, out[2]=steps,
+ * out[3]=max |e_pos|^2, out[4]=instances with status != 0 in the last step. */
+int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]);
+
+/* ---- multi-GPU: one engine per rank; the only collective is the reduction of the statistics
+ * vector (RCCL over xGMI).  The host exchanges the 128-byte unique id however it likes. */
+int mpcq_comm_unique_id(void* id128);
+int mpcq_comm_init(mpcq_engine* e, int32_t rank, int32_t nranks, const void* id128);
+/* sum (out[0..2], out[4]) / max (out[3]) over ranks; every rank receives the result */
+int mpcq_allreduce_tracking_stats(mpcq_engine* e, double out[5]);
+
+/* ---- state dump / restore (teacher-forced parity tests, checkpoint/resume).  Any pointer may
+ * be NULL.  X [B,N+1,13], U [B,N,4], mu [B,3,nb], C [B,3,nb,nb], x_pred_prev [B,13],
+ * has_prev [B], idx [B]. */
+int mpcq_get_state(mpcq_engine* e, double* X, double* U, double* mu, double* C, double* x_pred_prev,
+                   int32_t* has_prev, int32_t* idx);
+int mpcq_set_state(mpcq_engine* e, const double* X, const double* U, const double* mu, const double* C,
+                   const double* x_pred_prev, const int32_t* has_prev, const int32_t* idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCQ_H */

@@ -1,0 +1,557 @@
+// mpcq_api.hip — C ABI (include/mpcq.h) over the HIP kernels in mpcq_kernels.hpp.
+// Host side of the engine: device allocations, precision dispatch, launches on a private
+// stream, HIP-event timing, optional RCCL reduction of the swarm statistics.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mpcq.h"
+#include "mpcq_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(MPCQ_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+  } while (0)
+
+// ---- RCCL through dlopen (only loaded when a communicator is requested)
+struct Id128 { char b[128]; };  // ncclUniqueId (passed by value)
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void* l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!l) l = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!l) return fail(MPCQ_ERR_COMM, std::string("dlopen librccl.so: ") + dlerror());
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(l, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(l, "ncclCommInitRank");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(l, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(l, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(l, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) return fail(MPCQ_ERR_COMM, "librccl.so lacks nccl symbols");
+  g_rccl.lib = l;
+  return 0;
+}
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;
+
+// SPD inverse through Cholesky (K_x = K(X,X) + sn^2 I; np.linalg.inv in the reference, src/gp/RGP.py:157)
+bool spd_inverse(const std::vector<double>& A, int n, std::vector<double>& Ai) {
+  std::vector<double> G(A);
+  for (int j = 0; j < n; ++j) {
+    double d = G[j * n + j];
+    for (int k = 0; k < j; ++k) d -= G[j * n + k] * G[j * n + k];
+    if (!(d > 0)) return false;
+    d = std::sqrt(d);
+    G[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = G[i * n + j];
+      for (int k = 0; k < j; ++k) s -= G[i * n + k] * G[j * n + k];
+      G[i * n + j] = s / d;
+    }
+  }
+  std::vector<double> Gi(n * n, 0.0);
+  for (int j = 0; j < n; ++j) {
+    Gi[j * n + j] = 1.0 / G[j * n + j];
+    for (int i = j + 1; i < n; ++i) {
+      double s = 0;
+      for (int k = j; k < i; ++k) s -= G[i * n + k] * Gi[k * n + j];
+      Gi[i * n + j] = s / G[i * n + i];
+    }
+  }
+  Ai.assign(n * n, 0.0);
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b <= a; ++b) {
+      double s = 0;
+      for (int k = a; k < n; ++k) s += Gi[k * n + a] * Gi[k * n + b];
+      Ai[a * n + b] = Ai[b * n + a] = s;
+    }
+  return true;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ engine
+struct mpcq_engine {
+  virtual ~mpcq_engine() {}
+  mpcq_config cfg;
+  std::vector<double> basis, theta;
+  int B = 0, N = 0, nb = 0, threads = 64;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_time = 0;
+  bool have_traj = false, timed = false;
+  void* comm = nullptr;
+  int nranks = 1;
+  double* d_stats5 = nullptr;
+  virtual int init() = 0;
+  virtual int reset() = 0;
+  virtual int set_trajectories(const double*, const int32_t*, int32_t) = 0;
+  virtual int set_reference(const double*, const double*) = 0;
+  virtual int set_params(const double*) = 0;
+  virtual int solve(const double*) = 0;
+  virtual int get_x(int, double*) = 0;
+  virtual int get_u(int, double*) = 0;
+  virtual int get_cost(double*) = 0;
+  virtual int get_int(int which, int32_t*) = 0;
+  virtual int predict(const double*, const double*, double, double*) = 0;
+  virtual int regress(const double*, const double*) = 0;
+  virtual int get_rgp(double*, double*) = 0;
+  virtual int step(const double*, double*, double*) = 0;
+  virtual int step_device(const void*, void*) = 0;
+  virtual int sim_reset(const double*) = 0;
+  virtual int sim_steps(int, int, double) = 0;
+  virtual int sim_get(double*, double*) = 0;
+  virtual int stats(double*) = 0;
+  virtual int get_state(double*, double*, double*, double*, double*, int32_t*, int32_t*) = 0;
+  virtual int set_state(const double*, const double*, const double*, const double*, const double*, const int32_t*, const int32_t*) = 0;
+};
+
+namespace {
+
+template <typename T>
+struct EngineT : mpcq_engine {
+  mpcq::DevModel<T> m;
+  mpcq::DevState<T> st;
+  mpcq::Lds L;
+  size_t lds_bytes = 0;
+  T *d_basis = nullptr, *d_Kxinv = nullptr, *d_Kx = nullptr, *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr;
+  T *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
+  int* d_tlen = nullptr;
+  std::vector<T> hbuf;
+  std::vector<double> Kx;
+
+  ~EngineT() override {
+    void* ptrs[] = {st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
+                    st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5};
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+  }
+
+  template <typename P> int dalloc(P*& p, size_t n) {
+    HIP_TRY(hipMalloc((void**)&p, (n ? n : 1) * sizeof(*p)));
+    HIP_TRY(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(*p), stream));
+    return 0;
+  }
+  int h2d(T* dst, const double* src, size_t n) {
+    hbuf.resize(n);
+    for (size_t i = 0; i < n; ++i) hbuf[i] = (T)src[i];
+    HIP_TRY(hipMemcpyAsync(dst, hbuf.data(), n * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int d2h(double* dst, const T* src, size_t n) {
+    hbuf.resize(n);
+    HIP_TRY(hipMemcpyAsync(hbuf.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < n; ++i) dst[i] = (double)hbuf[i];
+    return 0;
+  }
+
+  int init() override {
+    const mpcq_config& c = cfg;
+    HIP_TRY(hipSetDevice(c.device));
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    if (const char* t = getenv("MPCQ_THREADS")) { int v = atoi(t); if (v == 64 || v == 128 || v == 256) threads = v; }
+    std::memset(&m, 0, sizeof(m));
+    std::memset(&st, 0, sizeof(st));
+    m.N = N; m.nb = nb; m.skip = c.skip; m.Tmax = 0; m.B = B;
+    const bool f32 = sizeof(T) == 4;
+    m.qp_max_iter = c.qp_max_iter > 0 ? c.qp_max_iter : 60;
+    m.qp_tol = (T)(c.qp_tol > 0 ? c.qp_tol : (f32 ? 2e-6 : 1e-11));
+    m.eps = f32 ? (T)6e-8 : (T)1.1e-16;
+    m.ipm_tol = f32 ? (T)1e-4 : (T)1e-6;
+    m.polish_max = f32 ? 12 : 8;
+    if (const char* t = getenv("MPCQ_IPM_TOL")) m.ipm_tol = (T)atof(t);
+    if (const char* t = getenv("MPCQ_POLISH_MAX")) m.polish_max = atoi(t);
+    if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;
+    m.h = (T)(c.T / c.N); m.dt_pred = (T)c.dt_pred;
+    m.mass = (T)c.mass; m.tmax = (T)c.max_thrust; m.g = (T)c.g; m.aero_drag = (T)c.aero_drag;
+    for (int i = 0; i < 3; ++i) { m.J[i] = (T)c.J[i]; m.rotor_drag[i] = (T)c.rotor_drag[i]; }
+    for (int i = 0; i < 4; ++i) {
+      m.xf[i] = (T)c.x_f[i]; m.yf[i] = (T)c.y_f[i]; m.zl[i] = (T)c.z_l_tau[i];
+      m.ulb[i] = (T)c.u_lb[i]; m.uub[i] = (T)c.u_ub[i]; m.uref[i] = (T)c.u_ref[i];
+    }
+    for (int i = 0; i < 17; ++i) m.W[i] = (T)c.W[i];
+    for (int i = 0; i < 13; ++i) m.We[i] = (T)c.W_e[i];
+    // RGP constants: K_x = K(X,X) + sn^2 I and its inverse (RGP.__init__, src/gp/RGP.py:140-157)
+    Kx.assign((size_t)3 * nb * nb, 0.0);
+    std::vector<double> Kxinv((size_t)3 * nb * nb, 0.0);
+    for (int d = 0; d < 3 && nb; ++d) {
+      const double Lh = theta[3 * d], sf = theta[3 * d + 1], sn = theta[3 * d + 2];
+      if (!(Lh > 0)) return fail(MPCQ_ERR_INVALID, "theta: length scale must be > 0");
+      m.L2inv[d] = (T)(1.0 / (Lh * Lh)); m.sf2[d] = (T)(sf * sf); m.sn2[d] = (T)(sn * sn);
+      std::vector<double> K(nb * nb), Ki;
+      for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < nb; ++j) {
+          const double dl = basis[d * nb + i] - basis[d * nb + j];
+          K[i * nb + j] = sf * sf * std::exp(-0.5 * dl * dl / (Lh * Lh)) + (i == j ? sn * sn : 0.0);
+        }
+      if (!spd_inverse(K, nb, Ki)) return fail(MPCQ_ERR_INVALID, "K_x is not positive definite");
+      std::copy(K.begin(), K.end(), Kx.begin() + (size_t)d * nb * nb);
+      std::copy(Ki.begin(), Ki.end(), Kxinv.begin() + (size_t)d * nb * nb);
+    }
+    int rc;
+    if ((rc = dalloc(d_basis, 3 * nb))) return rc;
+    if ((rc = dalloc(d_Kxinv, (size_t)3 * nb * nb))) return rc;
+    if ((rc = dalloc(d_Kx, (size_t)3 * nb * nb))) return rc;
+    if (nb) {
+      if ((rc = h2d(d_basis, basis.data(), 3 * nb))) return rc;
+      if ((rc = h2d(d_Kxinv, Kxinv.data(), (size_t)3 * nb * nb))) return rc;
+      if ((rc = h2d(d_Kx, Kx.data(), (size_t)3 * nb * nb))) return rc;
+    }
+    m.basis = d_basis; m.Kxinv = d_Kxinv;
+    const size_t Bz = B;
+    if ((rc = dalloc(st.X, Bz * (N + 1) * 13))) return rc;
+    if ((rc = dalloc(st.U, Bz * N * 4))) return rc;
+    if ((rc = dalloc(st.mu, Bz * 3 * nb))) return rc;
+    if ((rc = dalloc(st.C, Bz * 3 * nb * nb))) return rc;
+    if ((rc = dalloc(st.xpp, Bz * 13))) return rc;
+    if ((rc = dalloc(st.yref, Bz * N * 17))) return rc;
+    if ((rc = dalloc(st.yrefN, Bz * 13))) return rc;
+    if ((rc = dalloc(st.w, Bz * 4))) return rc;
+    if ((rc = dalloc(st.xpred, Bz * 13))) return rc;
+    if ((rc = dalloc(st.cost, Bz))) return rc;
+    if ((rc = dalloc(st.stats, Bz * 4))) return rc;
+    if ((rc = dalloc(st.has_prev, Bz))) return rc;
+    if ((rc = dalloc(st.idx, Bz))) return rc;
+    if ((rc = dalloc(st.status, Bz))) return rc;
+    if ((rc = dalloc(st.qp_iter, Bz))) return rc;
+    if ((rc = dalloc(d_tlen, Bz))) return rc;
+    if ((rc = dalloc(d_xin, Bz * 13))) return rc;
+    if ((rc = dalloc(d_uin, Bz * 4))) return rc;
+    if ((rc = dalloc(d_tmp, Bz * 13))) return rc;
+    if ((rc = dalloc(d_xs, Bz * 13))) return rc;
+    if ((rc = dalloc(d_vb, Bz * 3))) return rc;
+    if ((rc = dalloc(d_ad, Bz * 3))) return rc;
+    if ((rc = dalloc(d_stats5, 8))) return rc;
+    st.tlen = d_tlen; st.traj = nullptr; st.x_meas = d_xin;
+    L = mpcq::lds_layout(N, nb);
+    lds_bytes = (size_t)L.total * sizeof(T);
+    if (lds_bytes > 160 * 1024) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS (N/nb too large for this precision)");
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::step_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::regress_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    return reset();
+  }
+
+  int reset() override {
+    const size_t Bz = B;
+    HIP_TRY(hipMemsetAsync(st.X, 0, Bz * (N + 1) * 13 * sizeof(T), stream));
+    HIP_TRY(hipMemsetAsync(st.U, 0, Bz * N * 4 * sizeof(T), stream));
+    if (nb) HIP_TRY(hipMemsetAsync(st.mu, 0, Bz * 3 * nb * sizeof(T), stream));
+    HIP_TRY(hipMemsetAsync(st.xpp, 0, Bz * 13 * sizeof(T), stream));
+    HIP_TRY(hipMemsetAsync(st.stats, 0, Bz * 4 * sizeof(T), stream));
+    HIP_TRY(hipMemsetAsync(st.has_prev, 0, Bz * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(st.idx, 0, Bz * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(st.status, 0, Bz * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(st.qp_iter, 0, Bz * sizeof(int), stream));
+    if (nb) {  // C_0 = K_x for every instance and axis
+      std::vector<T> h((size_t)B * 3 * nb * nb);
+      for (size_t b = 0; b < Bz; ++b)
+        for (size_t i = 0; i < (size_t)3 * nb * nb; ++i) h[b * 3 * nb * nb + i] = (T)Kx[i];
+      HIP_TRY(hipMemcpyAsync(st.C, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  int set_trajectories(const double* traj, const int32_t* len, int32_t Tmax) override {
+    if (Tmax <= 0) return fail(MPCQ_ERR_INVALID, "Tmax must be positive");
+    for (int b = 0; b < B; ++b)
+      if (len[b] <= 0 || len[b] > Tmax) return fail(MPCQ_ERR_INVALID, "trajectory length out of range");
+    if (d_traj && m.Tmax != Tmax) { (void)hipFree(d_traj); d_traj = nullptr; }
+    if (!d_traj) HIP_TRY(hipMalloc((void**)&d_traj, (size_t)B * Tmax * 13 * sizeof(T)));
+    m.Tmax = Tmax;
+    int rc;
+    if ((rc = h2d(d_traj, traj, (size_t)B * Tmax * 13))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_tlen, len, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(st.idx, 0, (size_t)B * sizeof(int), stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    st.traj = d_traj;
+    have_traj = true;
+    return 0;
+  }
+  int set_reference(const double* yref, const double* yrefN) override {
+    int rc;
+    if ((rc = h2d(st.yref, yref, (size_t)B * N * 17))) return rc;
+    return h2d(st.yrefN, yrefN, (size_t)B * 13);
+  }
+  int set_params(const double* mu) override { return nb ? h2d(st.mu, mu, (size_t)B * 3 * nb) : 0; }
+
+  int launch_step(int mode) {
+    HIP_TRY(hipEventRecord(ev0, stream));
+    hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, st, mode);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, stream));
+    timed = true;
+    return 0;
+  }
+  int solve(const double* x0) override {
+    int rc;
+    if ((rc = h2d(d_xin, x0, (size_t)B * 13))) return rc;
+    st.x_meas = d_xin;
+    if ((rc = launch_step(0))) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int get_x(int stage, double* out) override {
+    if (stage < 0 || stage > N) return fail(MPCQ_ERR_INVALID, "stage out of range");
+    std::vector<double> all((size_t)B * (N + 1) * 13);
+    int rc;
+    if ((rc = d2h(all.data(), st.X, all.size()))) return rc;
+    for (int b = 0; b < B; ++b) std::memcpy(out + (size_t)b * 13, &all[((size_t)b * (N + 1) + stage) * 13], 13 * sizeof(double));
+    return 0;
+  }
+  int get_u(int stage, double* out) override {
+    if (stage < 0 || stage >= N) return fail(MPCQ_ERR_INVALID, "stage out of range");
+    std::vector<double> all((size_t)B * N * 4);
+    int rc;
+    if ((rc = d2h(all.data(), st.U, all.size()))) return rc;
+    for (int b = 0; b < B; ++b) std::memcpy(out + (size_t)b * 4, &all[((size_t)b * N + stage) * 4], 4 * sizeof(double));
+    return 0;
+  }
+  int get_cost(double* out) override { return d2h(out, st.cost, B); }
+  int get_int(int which, int32_t* out) override {
+    const int* src = which == 0 ? st.status : (which == 1 ? st.qp_iter : (which == 2 ? st.idx : st.has_prev));
+    HIP_TRY(hipMemcpyAsync(out, src, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int predict(const double* x, const double* u, double dt, double* out) override {
+    int rc;
+    if ((rc = h2d(d_xin, x, (size_t)B * 13))) return rc;
+    if ((rc = h2d(d_uin, u, (size_t)B * 4))) return rc;
+    hipLaunchKernelGGL(mpcq::predict_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xin, d_uin, (T)dt, d_tmp, B);
+    HIP_TRY(hipGetLastError());
+    return d2h(out, d_tmp, (size_t)B * 13);
+  }
+  int regress(const double* vb, const double* ad) override {
+    if (!nb) return fail(MPCQ_ERR_STATE, "engine has no RGP (nb = 0)");
+    int rc;
+    if ((rc = h2d(d_vb, vb, (size_t)B * 3))) return rc;
+    if ((rc = h2d(d_ad, ad, (size_t)B * 3))) return rc;
+    hipLaunchKernelGGL(mpcq::regress_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, st, d_vb, d_ad);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int get_rgp(double* mu, double* C) override {
+    int rc;
+    if (mu && nb && (rc = d2h(mu, st.mu, (size_t)B * 3 * nb))) return rc;
+    if (C && nb && (rc = d2h(C, st.C, (size_t)B * 3 * nb * nb))) return rc;
+    return 0;
+  }
+  int step(const double* x_meas, double* w_out, double* x_pred_out) override {
+    if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_step needs mpcq_set_trajectories first");
+    int rc;
+    if ((rc = h2d(d_xin, x_meas, (size_t)B * 13))) return rc;
+    st.x_meas = d_xin;
+    if ((rc = launch_step(mpcq::MODE_TRAJ | mpcq::MODE_POST))) return rc;
+    if ((rc = d2h(w_out, st.w, (size_t)B * 4))) return rc;
+    if (x_pred_out && (rc = d2h(x_pred_out, st.xpred, (size_t)B * 13))) return rc;
+    return 0;
+  }
+  int step_device(const void* d_x, void* d_w) override {
+    if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_step_device_async needs mpcq_set_trajectories first");
+    mpcq::DevState<T> s2 = st;
+    s2.x_meas = (const T*)d_x;
+    if (d_w) s2.w = (T*)d_w;
+    HIP_TRY(hipEventRecord(ev0, stream));
+    hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, stream));
+    timed = true;
+    return 0;
+  }
+  int sim_reset(const double* x0) override { return h2d(d_xs, x0, (size_t)B * 13); }
+  int sim_steps(int K, int n_sub, double sim_dt) override {
+    if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_sim_steps needs mpcq_set_trajectories first");
+    mpcq::DevState<T> s2 = st;
+    s2.x_meas = d_xs;
+    HIP_TRY(hipEventRecord(ev0, stream));
+    for (int k = 0; k < K; ++k) {
+      hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+      hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, (T)sim_dt, B);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, stream));
+    timed = true;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int sim_get(double* x, double* w) override {
+    int rc;
+    if ((rc = d2h(x, d_xs, (size_t)B * 13))) return rc;
+    if (w && (rc = d2h(w, st.w, (size_t)B * 4))) return rc;
+    return 0;
+  }
+  int stats(double* out5) override {
+    hipLaunchKernelGGL(mpcq::stats_kernel<T>, dim3(1), dim3(256), 5 * 256 * sizeof(double), stream, st.stats, st.status, B, d_stats5);
+    HIP_TRY(hipGetLastError());
+    if (out5) {
+      HIP_TRY(hipMemcpyAsync(out5, d_stats5, 5 * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return 0;
+  }
+  int get_state(double* X, double* U, double* mu, double* C, double* xpp, int32_t* hp, int32_t* idx) override {
+    int rc;
+    if (X && (rc = d2h(X, st.X, (size_t)B * (N + 1) * 13))) return rc;
+    if (U && (rc = d2h(U, st.U, (size_t)B * N * 4))) return rc;
+    if (mu && nb && (rc = d2h(mu, st.mu, (size_t)B * 3 * nb))) return rc;
+    if (C && nb && (rc = d2h(C, st.C, (size_t)B * 3 * nb * nb))) return rc;
+    if (xpp && (rc = d2h(xpp, st.xpp, (size_t)B * 13))) return rc;
+    if (hp && (rc = get_int(3, hp))) return rc;
+    if (idx && (rc = get_int(2, idx))) return rc;
+    return 0;
+  }
+  int set_state(const double* X, const double* U, const double* mu, const double* C, const double* xpp, const int32_t* hp,
+                const int32_t* idx) override {
+    int rc;
+    if (X && (rc = h2d(st.X, X, (size_t)B * (N + 1) * 13))) return rc;
+    if (U && (rc = h2d(st.U, U, (size_t)B * N * 4))) return rc;
+    if (mu && nb && (rc = h2d(st.mu, mu, (size_t)B * 3 * nb))) return rc;
+    if (C && nb && (rc = h2d(st.C, C, (size_t)B * 3 * nb * nb))) return rc;
+    if (xpp && (rc = h2d(st.xpp, xpp, (size_t)B * 13))) return rc;
+    if (hp) HIP_TRY(hipMemcpyAsync(st.has_prev, hp, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (idx) HIP_TRY(hipMemcpyAsync(st.idx, idx, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* mpcq_last_error(void) { return g_err.c_str(); }
+const char* mpcq_version(void) { return "mpcq 0.1 (gfx950)"; }
+
+int mpcq_create(const mpcq_config* c, mpcq_engine** out) {
+  if (!c || !out) return fail(MPCQ_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (c->batch <= 0 || c->N < 2 || c->N > 128 || c->nb < 0 || c->nb > 128 || c->skip < 1 || !(c->T > 0) || !(c->dt_pred > 0))
+    return fail(MPCQ_ERR_INVALID, "bad batch/N/nb/skip/T/dt_pred");
+  if (c->nb > 0 && (!c->basis || !c->theta)) return fail(MPCQ_ERR_INVALID, "nb > 0 needs basis and theta");
+  if (!(c->mass > 0) || !(c->J[0] > 0) || !(c->J[1] > 0) || !(c->J[2] > 0)) return fail(MPCQ_ERR_INVALID, "bad mass/inertia");
+  for (int i = 0; i < 4; ++i)
+    if (!(c->u_ub[i] > c->u_lb[i])) return fail(MPCQ_ERR_INVALID, "u_ub must exceed u_lb");
+  for (int i = 13; i < 17; ++i)
+    if (!(c->W[i] > 0)) return fail(MPCQ_ERR_INVALID, "input weights must be positive (strictly convex QP)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MPCQ_ERR_DEVICE, "no HIP device: libmpcq has no CPU path (the CPU restatement lives in oracle/ for tests only)");
+  if (c->device < 0 || c->device >= ndev) return fail(MPCQ_ERR_INVALID, "device ordinal out of range");
+  mpcq_engine* e = nullptr;
+  if (c->precision == MPCQ_PRECISION_F64) e = new EngineT<double>();
+  else if (c->precision == MPCQ_PRECISION_F32) e = new EngineT<float>();
+  else return fail(MPCQ_ERR_INVALID, "unknown precision");
+  e->cfg = *c;
+  e->B = c->batch; e->N = c->N; e->nb = c->nb;
+  if (c->nb) { e->basis.assign(c->basis, c->basis + 3 * c->nb); e->theta.assign(c->theta, c->theta + 9); }
+  e->cfg.basis = nullptr; e->cfg.theta = nullptr;
+  const int rc = e->init();
+  if (rc) { delete e; return rc; }
+  *out = e;
+  return 0;
+}
+int mpcq_destroy(mpcq_engine* e) { delete e; return 0; }
+#define CHK(e) if (!(e)) return fail(MPCQ_ERR_INVALID, "null engine")
+int mpcq_reset(mpcq_engine* e) { CHK(e); return e->reset(); }
+int mpcq_set_trajectories(mpcq_engine* e, const double* t, const int32_t* len, int32_t Tmax) { CHK(e); if (!t || !len) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_trajectories(t, len, Tmax); }
+int mpcq_set_reference(mpcq_engine* e, const double* y, const double* yN) { CHK(e); if (!y || !yN) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_reference(y, yN); }
+int mpcq_set_params(mpcq_engine* e, const double* mu) { CHK(e); if (!mu && e->nb) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_params(mu); }
+int mpcq_solve(mpcq_engine* e, const double* x0) { CHK(e); if (!x0) return fail(MPCQ_ERR_INVALID, "x_init has to be set before running the optimization"); return e->solve(x0); }
+int mpcq_get_x(mpcq_engine* e, int32_t s, double* o) { CHK(e); return e->get_x(s, o); }
+int mpcq_get_u(mpcq_engine* e, int32_t s, double* o) { CHK(e); return e->get_u(s, o); }
+int mpcq_get_cost(mpcq_engine* e, double* o) { CHK(e); return e->get_cost(o); }
+int mpcq_get_status(mpcq_engine* e, int32_t* o) { CHK(e); return e->get_int(0, o); }
+int mpcq_get_qp_iter(mpcq_engine* e, int32_t* o) { CHK(e); return e->get_int(1, o); }
+int mpcq_get_stats(mpcq_engine* e, double* t) {
+  CHK(e);
+  if (e->timed) {
+    float ms = 0;
+    if (hipEventSynchronize(e->ev1) == hipSuccess && hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) e->last_time = ms * 1e-3;
+  }
+  if (t) *t = e->last_time;
+  return 0;
+}
+int mpcq_predict_nominal(mpcq_engine* e, const double* x, const double* u, double dt, double* o) { CHK(e); return e->predict(x, u, dt, o); }
+int mpcq_rgp_regress(mpcq_engine* e, const double* vb, const double* ad) { CHK(e); return e->regress(vb, ad); }
+int mpcq_get_rgp(mpcq_engine* e, double* mu, double* C) { CHK(e); return e->get_rgp(mu, C); }
+int mpcq_step(mpcq_engine* e, const double* x, double* w, double* xp) { CHK(e); if (!x || !w) return fail(MPCQ_ERR_INVALID, "null argument"); return e->step(x, w, xp); }
+int mpcq_step_device_async(mpcq_engine* e, const void* dx, void* dw) { CHK(e); if (!dx) return fail(MPCQ_ERR_INVALID, "null argument"); return e->step_device(dx, dw); }
+int mpcq_synchronize(mpcq_engine* e) { CHK(e); HIP_TRY(hipStreamSynchronize(e->stream)); return 0; }
+void* mpcq_stream(mpcq_engine* e) { return e ? (void*)e->stream : nullptr; }
+int mpcq_sim_reset(mpcq_engine* e, const double* x0) { CHK(e); return e->sim_reset(x0); }
+int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { CHK(e); return e->sim_steps(K, n_sub, sim_dt); }
+int mpcq_sim_get_state(mpcq_engine* e, double* x, double* w) { CHK(e); return e->sim_get(x, w); }
+int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]) { CHK(e); return e->stats(out); }
+
+int mpcq_comm_unique_id(void* id128) {
+  int rc = rccl_load();
+  if (rc) return rc;
+  const int r = g_rccl.GetUniqueId(id128);
+  if (r) return fail(MPCQ_ERR_COMM, std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+  return 0;
+}
+int mpcq_comm_init(mpcq_engine* e, int32_t rank, int32_t nranks, const void* id128) {
+  CHK(e);
+  int rc = rccl_load();
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  Id128 id;
+  std::memcpy(&id, id128, sizeof(id));
+  const int r = g_rccl.CommInitRank(&e->comm, nranks, id, rank);
+  if (r) return fail(MPCQ_ERR_COMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+  e->nranks = nranks;
+  return 0;
+}
+int mpcq_allreduce_tracking_stats(mpcq_engine* e, double out[5]) {
+  CHK(e);
+  int rc = e->stats(nullptr);  // local 5-vector on the device
+  if (rc) return rc;
+  if (e->comm) {
+    // slots 0,1,2,4 sum; slot 3 max: reduce [s0,s1,s2,0,s4] with SUM into d[0..4], [s3] with MAX into d[5]
+    double* d = e->d_stats5;
+    HIP_TRY(hipMemcpyAsync(d + 5, d + 3, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(d + 3, 0, sizeof(double), e->stream));
+    int r = g_rccl.AllReduce(d, d, 5, NCCL_FLOAT64, NCCL_SUM, e->comm, e->stream);
+    if (!r) r = g_rccl.AllReduce(d + 5, d + 5, 1, NCCL_FLOAT64, NCCL_MAX, e->comm, e->stream);
+    if (r) return fail(MPCQ_ERR_COMM, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+    HIP_TRY(hipMemcpyAsync(d + 3, d + 5, sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(out, e->d_stats5, 5 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return 0;
+}
+int mpcq_get_state(mpcq_engine* e, double* X, double* U, double* mu, double* C, double* xpp, int32_t* hp, int32_t* idx) { CHK(e); return e->get_state(X, U, mu, C, xpp, hp, idx); }
+int mpcq_set_state(mpcq_engine* e, const double* X, const double* U, const double* mu, const double* C, const double* xpp, const int32_t* hp, const int32_t* idx) { CHK(e); return e->set_state(X, U, mu, C, xpp, hp, idx); }
+
+}  // extern "C"

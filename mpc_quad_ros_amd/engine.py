@@ -1,0 +1,173 @@
+"""Batched engine handle over the C ABI (include/mpcq.h): B quadrotors advanced in lockstep on
+one MI355X, all state resident in HBM.  Thin: every method is one C call plus numpy marshalling."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .params import NU, NX, NY, EngineConfig
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig, lib_path: str | None = None):
+        self.cfg = cfg
+        self.lib = _lib.load(lib_path)
+        self._c = cfg.to_c()
+        h = ctypes.c_void_p()
+        self._check(self.lib.mpcq_create(ctypes.byref(self._c), ctypes.byref(h)))
+        self.h = h
+        self.B, self.N, self.nb = cfg.batch, cfg.N, cfg.nb
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.MpcqError(f"mpcq error {rc}: {self.lib.mpcq_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mpcq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _f(a, shape=None):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return a if shape is None else a.reshape(shape)
+
+    # ---- state
+    def reset(self):
+        self._check(self.lib.mpcq_reset(self.h))
+
+    def set_trajectories(self, traj, lengths=None):
+        traj = self._f(traj)
+        if traj.ndim != 3 or traj.shape[0] != self.B or traj.shape[2] != NX:
+            raise ValueError(f"traj must be [B={self.B}, T, 13]")
+        if lengths is None:
+            lengths = np.full(self.B, traj.shape[1])
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        self._check(self.lib.mpcq_set_trajectories(self.h, _lib.d(traj), _lib.i(lengths), traj.shape[1]))
+
+    def set_reference(self, yref, yrefN):
+        yref = self._f(yref, (self.B, self.N, NY))
+        yrefN = self._f(yrefN, (self.B, NX))
+        self._check(self.lib.mpcq_set_reference(self.h, _lib.d(yref), _lib.d(yrefN)))
+
+    def set_params(self, mu):
+        mu = self._f(mu, (self.B, 3 * self.nb))
+        self._check(self.lib.mpcq_set_params(self.h, _lib.d(mu)))
+
+    def get_state(self):
+        B, N, nb = self.B, self.N, self.nb
+        s = dict(X=np.zeros((B, N + 1, NX)), U=np.zeros((B, N, NU)), mu=np.zeros((B, 3, nb)),
+                 C=np.zeros((B, 3, nb, nb)), x_pred_prev=np.zeros((B, NX)),
+                 has_prev=np.zeros(B, np.int32), idx=np.zeros(B, np.int32))
+        self._check(self.lib.mpcq_get_state(self.h, _lib.d(s["X"]), _lib.d(s["U"]), _lib.d(s["mu"]), _lib.d(s["C"]),
+                                            _lib.d(s["x_pred_prev"]), _lib.i(s["has_prev"]), _lib.i(s["idx"])))
+        return s
+
+    def set_state(self, X=None, U=None, mu=None, C=None, x_pred_prev=None, has_prev=None, idx=None):
+        g = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        X, U, mu, C, xp = (self._f(a) for a in (X, U, mu, C, x_pred_prev))
+        hp, ix = g(has_prev), g(idx)
+        self._check(self.lib.mpcq_set_state(self.h, _lib.d(X), _lib.d(U), _lib.d(mu), _lib.d(C), _lib.d(xp),
+                                            _lib.i(hp), _lib.i(ix)))
+
+    # ---- explicit path (acados-style set / solve / get)
+    def solve(self, x0):
+        x0 = self._f(x0, (self.B, NX))
+        self._check(self.lib.mpcq_solve(self.h, _lib.d(x0)))
+
+    def get_x(self, stage):
+        out = np.zeros((self.B, NX))
+        self._check(self.lib.mpcq_get_x(self.h, stage, _lib.d(out)))
+        return out
+
+    def get_u(self, stage):
+        out = np.zeros((self.B, NU))
+        self._check(self.lib.mpcq_get_u(self.h, stage, _lib.d(out)))
+        return out
+
+    def get_cost(self):
+        out = np.zeros(self.B)
+        self._check(self.lib.mpcq_get_cost(self.h, _lib.d(out)))
+        return out
+
+    def get_status(self):
+        out = np.zeros(self.B, np.int32)
+        self._check(self.lib.mpcq_get_status(self.h, _lib.i(out)))
+        return out
+
+    def get_qp_iter(self):
+        out = np.zeros(self.B, np.int32)
+        self._check(self.lib.mpcq_get_qp_iter(self.h, _lib.i(out)))
+        return out
+
+    def get_time(self):
+        t = ctypes.c_double()
+        self._check(self.lib.mpcq_get_stats(self.h, ctypes.byref(t)))
+        return t.value
+
+    def predict_nominal(self, x, u, dt):
+        x, u = self._f(x, (self.B, NX)), self._f(u, (self.B, NU))
+        out = np.zeros((self.B, NX))
+        self._check(self.lib.mpcq_predict_nominal(self.h, _lib.d(x), _lib.d(u), float(dt), _lib.d(out)))
+        return out
+
+    def rgp_regress(self, v_body, a_drag):
+        vb, ad = self._f(v_body, (self.B, 3)), self._f(a_drag, (self.B, 3))
+        self._check(self.lib.mpcq_rgp_regress(self.h, _lib.d(vb), _lib.d(ad)))
+
+    def get_rgp(self):
+        mu = np.zeros((self.B, 3, self.nb))
+        C = np.zeros((self.B, 3, self.nb, self.nb))
+        self._check(self.lib.mpcq_get_rgp(self.h, _lib.d(mu), _lib.d(C)))
+        return mu, C
+
+    # ---- fused path
+    def step(self, x_meas):
+        x = self._f(x_meas, (self.B, NX))
+        w = np.zeros((self.B, NU))
+        xp = np.zeros((self.B, NX))
+        self._check(self.lib.mpcq_step(self.h, _lib.d(x), _lib.d(w), _lib.d(xp)))
+        return w, xp
+
+    def sim_reset(self, x0):
+        x0 = self._f(x0, (self.B, NX))
+        self._check(self.lib.mpcq_sim_reset(self.h, _lib.d(x0)))
+
+    def sim_steps(self, K, n_sub, sim_dt=5e-3):
+        self._check(self.lib.mpcq_sim_steps(self.h, int(K), int(n_sub), float(sim_dt)))
+
+    def sim_get_state(self):
+        x = np.zeros((self.B, NX))
+        w = np.zeros((self.B, NU))
+        self._check(self.lib.mpcq_sim_get_state(self.h, _lib.d(x), _lib.d(w)))
+        return x, w
+
+    def get_tracking_stats(self):
+        out = np.zeros(5)
+        self._check(self.lib.mpcq_get_tracking_stats(self.h, _lib.d(out)))
+        return out
+
+    # ---- multi-GPU statistics
+    def comm_unique_id(self) -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        self._check(self.lib.mpcq_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, nranks, uid: bytes):
+        buf = ctypes.create_string_buffer(uid, 128)
+        self._check(self.lib.mpcq_comm_init(self.h, rank, nranks, buf))
+
+    def allreduce_tracking_stats(self):
+        out = np.zeros(5)
+        self._check(self.lib.mpcq_allreduce_tracking_stats(self.h, _lib.d(out)))
+        return out

@@ -1,0 +1,100 @@
+"""Seeded synthetic random-waypoint reference trajectories (host side, numpy).
+
+Family: the node's 'random' request — start at the hover point, 3 waypoints uniform in a
++-[5,5,5] m cube centred at [0,0,7.5] (src/trajectory_generator_node.py:159-167,
+src/trajectory_generation/TrajectoryGenerator.py:133-163), v_max / a_max limits, sampled at 100 Hz,
+q_ref = [1,0,0,0], rates 0 (TrajectoryGenerator.py:223-244).  The reference shells out to a
+prebuilt min-snap binary (genTrajectory) that cannot run here; this generator replaces it with a
+C2 cubic-spline path through the waypoints traversed with a rest-to-rest quintic time law whose
+duration is stretched until max|v| <= v_max and max|a| <= a_max.
+
+Instance i of a swarm draws from Generator(seed, i): the trajectory of a quadrotor depends only on
+(seed, global index), never on how the swarm is sharded over ranks.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+HOVER = np.array([0.0, 0.0, 3.0])          # src/mpc_controller_node.py:119
+NX = 13
+
+
+def _natural_cubic_spline(P):
+    """C2 natural cubic spline through P[0..n] at unit knot spacing -> per-segment coefficients."""
+    n = P.shape[0] - 1
+    A = np.zeros((n + 1, n + 1))
+    rhs = np.zeros((n + 1, P.shape[1]))
+    A[0, 0] = A[n, n] = 1.0
+    for i in range(1, n):
+        A[i, i - 1], A[i, i], A[i, i + 1] = 1.0, 4.0, 1.0
+        rhs[i] = 6.0 * (P[i + 1] - 2 * P[i] + P[i - 1])
+    M = np.linalg.solve(A, rhs)                      # second derivatives at the knots
+    a = P[:-1]
+    b = (P[1:] - P[:-1]) - (2 * M[:-1] + M[1:]) / 6.0
+    c = M[:-1] / 2.0
+    d = (M[1:] - M[:-1]) / 6.0
+    return a, b, c, d
+
+
+def _eval_path(coef, s):
+    a, b, c, d = coef
+    n = a.shape[0]
+    k = np.minimum(np.floor(s).astype(int), n - 1)
+    t = (s - k)[:, None]
+    p = a[k] + t * (b[k] + t * (c[k] + t * d[k]))
+    dp = b[k] + t * (2 * c[k] + 3 * t * d[k])
+    ddp = 2 * c[k] + 6 * t * d[k]
+    return p, dp, ddp
+
+
+def random_waypoint_trajectory(seed: int, index: int, v_max: float = 12.0, a_max: float = 12.0,
+                               dt: float = 0.01, num_waypoints: int = 3, hsize=(5.0, 5.0, 5.0),
+                               start=HOVER):
+    """Returns x_ref [T, 13] sampled every dt (p, q=[1,0,0,0], v, r=0)."""
+    rng = np.random.default_rng([int(seed), int(index)])
+    hs = np.asarray(hsize, dtype=float)
+    centre = np.array([0.0, 0.0, 1.5 * hs[2]])
+    wps = [np.asarray(start, dtype=float)]
+    for _ in range(num_waypoints):
+        wps.append(rng.uniform(-hs, hs) + centre)
+    P = np.array(wps)
+    coef = _natural_cubic_spline(P)
+    n = P.shape[0] - 1
+    # rest-to-rest quintic time law s(tau) = n*(10 tau^3 - 15 tau^4 + 6 tau^5), tau = t/D
+    tau = np.linspace(0.0, 1.0, 2001)
+    s = n * (10 * tau**3 - 15 * tau**4 + 6 * tau**5)
+    ds = n * (30 * tau**2 - 60 * tau**3 + 30 * tau**4)
+    dds = n * (60 * tau - 180 * tau**2 + 120 * tau**3)
+    p, dp, ddp = _eval_path(coef, s)
+    v1 = np.linalg.norm(dp * ds[:, None], axis=1).max()                       # |v| at D = 1
+    a1 = np.linalg.norm(ddp * (ds**2)[:, None] + dp * dds[:, None], axis=1).max()
+    D = max(v1 / v_max, np.sqrt(a1 / a_max), 1.0)
+    ts = np.arange(0.0, D, dt)                                                # as save_evals_csv: arange(0, duration, dt)
+    tau = ts / D
+    s = n * (10 * tau**3 - 15 * tau**4 + 6 * tau**5)
+    ds = n * (30 * tau**2 - 60 * tau**3 + 30 * tau**4) / D
+    p, dp, _ = _eval_path(coef, s)
+    x = np.zeros((len(ts), NX))
+    x[:, 0:3] = p
+    x[:, 3] = 1.0
+    x[:, 7:10] = dp * ds[:, None]
+    return x
+
+
+def swarm_trajectories(seed: int, first_index: int, count: int, **kw):
+    """Padded batch for Engine.set_trajectories: (traj [count, Tmax, 13], lengths [count])."""
+    trajs = [random_waypoint_trajectory(seed, first_index + i, **kw) for i in range(count)]
+    lens = np.array([t.shape[0] for t in trajs], dtype=np.int32)
+    Tmax = int(lens.max())
+    out = np.zeros((count, Tmax, NX))
+    for i, t in enumerate(trajs):
+        out[i, :t.shape[0]] = t
+        out[i, t.shape[0]:] = t[-1]
+    return out, lens
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous block partition of `total` instances over `world` ranks."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, base + (1 if rank < rem else 0)

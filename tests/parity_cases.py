@@ -1,0 +1,122 @@
+"""Parity cases shared by the GPU tests (real libmpcq.so) and the lane-emulator tests (same
+product sources compiled for the host, tests/wave_emu).  Every case drives the engine under test
+and the fp64 CPU oracle with identical inputs through the same C-ABI-shaped surface.
+
+Tolerances (relative control deviation, north_star budget 1e-4):
+  F64 device path: 1e-7 teacher-forced (observed <= 3e-10), 1e-6 free-running on contractive windows.
+"""
+import numpy as np
+
+from helpers import config_for_log, load_golden, random_states
+from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+from mpc_quad_ros_amd.trajectories import swarm_trajectories
+from oracle.oracle import OracleEngine
+
+TOL_TF = {0: 1e-7, 1: 1e-4}     # teacher-forced, by precision code
+TOL_FREE = {0: 1e-6, 1: 1e-3}
+
+
+def rel_err(a, b, floor=1e-3):
+    return np.abs(a - b).max() / max(np.abs(b).max(), floor)
+
+
+def case_teacher_forced_log(make_engine, name, K, precision=0, check_rgp=True):
+    """P1: before every step the engine state is overwritten with the oracle's, so each step
+    isolates arithmetic: same (X,U,mu,C,x_pred_prev,idx) in -> compare w, x_pred, cost, mu, C."""
+    g = load_golden(name)
+    cfg = config_for_log(g, precision=precision)
+    e, o = make_engine(cfg), OracleEngine(config_for_log(g))
+    e.set_trajectories(g["x_ref"][None]); o.set_trajectories(g["x_ref"][None])
+    worst = 0.0
+    for k in range(K):
+        e.set_state(**o.get_state())
+        w, xp = e.step(g["x_odom"][k][None])
+        wo, xpo = o.step(g["x_odom"][k][None])
+        assert e.get_status()[0] == 0, (k, e.get_status())
+        worst = max(worst, rel_err(w, wo))
+        assert rel_err(w, wo) < TOL_TF[precision], (k, rel_err(w, wo))
+        assert rel_err(xp, xpo, 1.0) < TOL_TF[precision]
+        assert abs(e.get_cost()[0] - o.get_cost()[0]) <= TOL_TF[precision] * max(1.0, o.get_cost()[0])
+        if cfg.nb and check_rgp:
+            mu, C = e.get_rgp(); muo, Co = o.get_rgp()
+            assert rel_err(mu, muo, 1.0) < (1e-10 if precision == 0 else 1e-4)
+            assert rel_err(C, Co, 1e-2) < (1e-10 if precision == 0 else 1e-4)
+        se, so = e.get_state(), o.get_state()
+        assert np.array_equal(se["idx"], so["idx"]) and np.array_equal(se["has_prev"], so["has_prev"])
+    return worst
+
+
+def case_free_running_log(make_engine, name, K, precision=0):
+    """P2: engine and oracle run independently from the cold start on a contractive window."""
+    g = load_golden(name)
+    e, o = make_engine(config_for_log(g, precision=precision)), OracleEngine(config_for_log(g))
+    e.set_trajectories(g["x_ref"][None]); o.set_trajectories(g["x_ref"][None])
+    worst = 0.0
+    for k in range(K):
+        w, _ = e.step(g["x_odom"][k][None])
+        wo, _ = o.step(g["x_odom"][k][None])
+        worst = max(worst, rel_err(w, wo))
+    assert worst < TOL_FREE[precision], worst
+    # and against the reference's own logged acados outputs
+    assert np.abs(w[0] - g["w_odom"][K - 1]).max() < 1e-4
+    return worst
+
+
+def case_explicit_api(make_engine, B=4, N=10, nb=10, precision=0, seed=0):
+    """acados-style path: set_reference / set_params / solve / get, predict_nominal, rgp_regress."""
+    rng = np.random.default_rng(seed)
+    kw = dict(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, dt_pred=0.01)
+    if nb:
+        kw.update(basis=rgp_basis_linspace(12.0, nb), theta=[1.0, 0.1, 0.1])
+    e, o = make_engine(EngineConfig(precision=precision, **kw)), OracleEngine(EngineConfig(**kw))
+    x0 = random_states(rng, B, 0.3)
+    xr = random_states(rng, B, 0.3)
+    yref = np.zeros((B, N, 17)); yref[:, :, :13] = xr[:, None, :]; yref[:, :, 13:] = 0.16
+    yref[:, :, 0] += np.linspace(0, 1, N)[None, :]
+    yrefN = yref[:, -1, :13].copy()
+    mu = rng.normal(0, 0.5, (B, 3 * nb))
+    for eng in (e, o):
+        eng.set_reference(yref, yrefN)
+        if nb:
+            eng.set_params(mu)
+    for it in range(3):
+        e.solve(x0); o.solve(x0)
+        assert (e.get_status() == 0).all()
+        for stage in (0, 1, N - 1):
+            assert rel_err(e.get_u(stage), o.get_u(stage)) < TOL_TF[precision] * (10 if it else 1)
+        for stage in (0, 1, N):
+            assert rel_err(e.get_x(stage), o.get_x(stage), 1.0) < TOL_TF[precision] * (10 if it else 1)
+        assert np.abs(e.get_x(0) - x0).max() < 1e-6
+        assert rel_err(e.get_cost(), o.get_cost(), 1.0) < TOL_TF[precision] * 10
+    u = rng.uniform(0, 1, (B, 4))
+    assert rel_err(e.predict_nominal(x0, u, 0.01), o.predict_nominal(x0, u, 0.01), 1.0) < (1e-13 if precision == 0 else 1e-5)
+    if nb:
+        for _ in range(3):
+            vb, ad = rng.normal(0, 4, (B, 3)), rng.normal(0, 2, (B, 3))
+            e.rgp_regress(vb, ad); o.rgp_regress(vb, ad)
+        mu_e, C_e = e.get_rgp(); mu_o, C_o = o.get_rgp()
+        assert rel_err(mu_e, mu_o, 1.0) < (1e-11 if precision == 0 else 1e-4)
+        assert rel_err(C_e, C_o, 1e-2) < (1e-11 if precision == 0 else 1e-4)
+
+
+def case_swarm_closed_loop(make_engine, B, N, nb, K, precision=0, seed=1, plant_sub=2):
+    """Synthetic random-waypoint swarm (the bench workload family), host-driven closed loop with the
+    oracle's drag plant; engine and oracle free-running side by side on identical measurements."""
+    kw = dict(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, dt_pred=0.01)
+    if nb:
+        kw.update(basis=rgp_basis_linspace(12.0, nb), theta=[1.0, 0.1, 0.1])
+    e, o = make_engine(EngineConfig(precision=precision, **kw)), OracleEngine(EngineConfig(**kw))
+    traj, lens = swarm_trajectories(seed, 0, B)
+    e.set_trajectories(traj, lens); o.set_trajectories(traj, lens)
+    x = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    worst = 0.0
+    for k in range(K):
+        w, xp = e.step(x)
+        wo, xpo = o.step(x)
+        assert (e.get_status() == 0).all(), (k, e.get_status())
+        worst = max(worst, rel_err(w, wo))
+        for _ in range(plant_sub):
+            x = o.plant_update(x, wo, 5e-3)
+    se, so = e.get_tracking_stats(), o.get_tracking_stats()
+    assert np.allclose(se[:4], so, rtol=1e-6 if precision == 0 else 1e-3, atol=1e-9)
+    return worst

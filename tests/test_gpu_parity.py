@@ -1,0 +1,113 @@
+"""Parity of the HIP path (libmpcq.so through the C ABI) against the fp64 CPU oracle on a real
+MI355X.  Run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from mpc_quad_ros_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+
+def make(cfg):
+    return Engine(cfg)
+
+
+def test_library_is_hip_and_device_present():
+    from mpc_quad_ros_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.mpcq_version()
+
+
+@pytest.mark.parametrize("name,K", [
+    ("log_traj1_v10_a10_gp0.npz", 60), ("log_traj0_v10_a10_gp2.npz", 110), ("log_traj0_v15_a5_gp2.npz", 150),
+    ("log_trajectory_v15_a5_gp2.npz", 80), ("log_traj2_v10_a10_gp2.npz", 100), ("log_traj1_v15_a5_gp2.npz", 45)])
+def test_teacher_forced_against_oracle_on_reference_logs(name, K):
+    worst = pc.case_teacher_forced_log(make, name, K)
+    print(name, "worst relative control deviation", worst)
+
+
+@pytest.mark.parametrize("name,K", [("log_traj1_v10_a10_gp0.npz", 200), ("log_traj0_v10_a10_gp2.npz", 110),
+                                    ("log_traj0_v15_a5_gp2.npz", 150)])
+def test_free_running_on_contractive_windows(name, K):
+    pc.case_free_running_log(make, name, K)
+
+
+def test_gazebo_hummingbird_log_strided_chunks():
+    from helpers import config_for_log, load_golden
+    g = load_golden("log_gazebo_traj0_v12_a12_gp0.npz")
+    e = make(config_for_log(g))
+    J = int(g["junction"])
+    e.set_trajectories(np.repeat(g["x_ref"][0][None], 3, axis=0)[None])
+    e.set_state(idx=np.array([5]))
+    err = []
+    for k in range(300):
+        if k == J:
+            e.set_trajectories(g["x_ref"][J:][None])
+        w, xp = e.step(g["x_odom"][k][None])
+        err.append(np.abs(w[0] - g["w_odom"][k]).max())
+        assert np.abs(xp[0] - e.predict_nominal(g["x_odom"][k][None], w, 0.01)[0]).max() < 1e-14
+    assert max(err[6:]) < 1e-7       # against the real acados outputs
+
+
+@pytest.mark.parametrize("N,nb", [(10, 10), (20, 10), (20, 20), (5, 0), (20, 0)])
+def test_explicit_api(N, nb):
+    pc.case_explicit_api(make, B=8, N=N, nb=nb)
+
+
+def test_swarm_closed_loop_config2_shape():
+    # BASELINE config 2 family at a size the oracle finishes in seconds: B=64, N=20, nb=10
+    worst = pc.case_swarm_closed_loop(make, B=64, N=20, nb=10, K=40)
+    print("swarm worst relative control deviation", worst)
+    assert worst < 1e-6
+
+
+def test_long_horizon_config5_shape():
+    worst = pc.case_swarm_closed_loop(make, B=4, N=50, nb=50, K=6)
+    assert worst < 1e-6
+
+
+def test_full_batch_properties():
+    """BASELINE config 2 at full size (B=1024): size-independent properties instead of the oracle:
+    permutation equivariance over instances, determinism, bounds, bit-exact cursor bookkeeping."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N, nb = 1024, 20, 10
+    cfg = lambda: EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb))
+    traj, lens = swarm_trajectories(3, 0, B)
+    perm = np.random.default_rng(0).permutation(B)
+    e1, e2 = make(cfg()), make(cfg())
+    e1.set_trajectories(traj, lens); e2.set_trajectories(traj[perm], lens[perm])
+    x = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    x[:, :3] += np.random.default_rng(1).normal(0, 0.05, (B, 3))
+    for k in range(5):
+        w1, xp1 = e1.step(x)
+        w2, xp2 = e2.step(x[perm])
+        assert np.array_equal(w1[perm], w2) and np.array_equal(xp1[perm], xp2)
+        assert w1.min() >= 0.0 and w1.max() <= 1.0
+        assert (e1.get_status() == 0).all()
+        x = xp1
+    assert np.array_equal(e1.get_state()["idx"], np.full(B, 5))
+    s1, s2 = e1.get_tracking_stats(), e2.get_tracking_stats()
+    assert s1[2] == 5 * B and np.allclose(s1, s2, rtol=1e-12)
+
+
+def test_device_closed_loop_matches_host_driven_loop():
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    from oracle.oracle import OracleEngine
+    B, N, nb, K = 16, 20, 10, 12
+    kw = dict(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb))
+    e, o = make(EngineConfig(**kw)), OracleEngine(EngineConfig(**kw))
+    traj, lens = swarm_trajectories(5, 0, B)
+    e.set_trajectories(traj, lens); o.set_trajectories(traj, lens)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    e.sim_reset(x0)
+    e.sim_steps(K, 2, 5e-3)
+    x = x0
+    for k in range(K):
+        w, _ = o.step(x)
+        for _ in range(2):
+            x = o.plant_update(x, w, 5e-3)
+    xe, we = e.sim_get_state()
+    assert np.abs(xe - x).max() < 1e-7 and np.abs(we - w).max() < 1e-7

@@ -1,0 +1,90 @@
+// tests/wave_emu/hip/hip_runtime.h — TEST-ONLY lane-level emulator of the HIP constructs the
+// mpcq kernels use, so the *unchanged* product sources (mpc_quad_ros_amd/csrc/*.hip|hpp) can be
+// compiled for the host and their lane logic debugged and regression-tested in a container
+// without a GPU.  Each workgroup lane is a ucontext fiber; __syncthreads() and __shfl_xor() are
+// cooperative rendezvous points; lanes of a phase run one after another (order selectable, so
+// a missing barrier shows up as an order-dependent result).
+//
+// NOT part of the product: libmpcq.so is always built by hipcc for gfx950 and has no CPU path.
+// The library built from this shim is named libmpcq_emu.so and is loaded only by tests that ask
+// for it explicitly.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __device__
+#define __host__
+#define __global__
+#define __shared__
+#define __align__(n) alignas(n)
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace emu {
+struct Lane { dim3 tid, bid, bdim, gdim; };
+extern Lane* cur;
+void sync();
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+uint64_t* exchange();  // one 8-byte slot per lane
+}  // namespace emu
+
+#define threadIdx (emu::cur->tid)
+#define blockIdx (emu::cur->bid)
+#define blockDim (emu::cur->bdim)
+#define gridDim (emu::cur->gdim)
+
+inline void __syncthreads() { emu::sync(); }
+template <typename T> inline T __shfl_xor(T v, int mask) {
+  static_assert(sizeof(T) <= 8, "shuffle payload");
+  uint64_t* ex = emu::exchange();
+  const unsigned t = emu::cur->tid.x;
+  uint64_t raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  ex[t] = raw;
+  emu::sync();
+  const unsigned src = (t & ~63u) | ((t ^ (unsigned)mask) & 63u);
+  raw = ex[src];
+  emu::sync();
+  T r;
+  std::memcpy(&r, &raw, sizeof(T));
+  return r;
+}
+inline float __expf(float x) { return std::exp(x); }
+
+// ---- host runtime subset
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+typedef void* hipStream_t;
+typedef struct emuEvent* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+constexpr unsigned hipStreamNonBlocking = 1;
+constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
+const char* hipGetErrorString(hipError_t);
+hipError_t hipGetDeviceCount(int*);
+hipError_t hipSetDevice(int);
+hipError_t hipMalloc(void**, size_t);
+hipError_t hipFree(void*);
+hipError_t hipMemset(void*, int, size_t);
+hipError_t hipMemsetAsync(void*, int, size_t, hipStream_t);
+hipError_t hipMemcpyAsync(void*, const void*, size_t, hipMemcpyKind, hipStream_t);
+hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned);
+hipError_t hipStreamSynchronize(hipStream_t);
+hipError_t hipStreamDestroy(hipStream_t);
+hipError_t hipEventCreate(hipEvent_t*);
+hipError_t hipEventDestroy(hipEvent_t);
+hipError_t hipEventRecord(hipEvent_t, hipStream_t);
+hipError_t hipEventSynchronize(hipEvent_t);
+hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t);
+hipError_t hipGetLastError();
+hipError_t hipFuncSetAttribute(const void*, int, int);
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
