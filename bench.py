@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — batched MPC+RGP control steps/s (BASELINE.json metric) on MI355X.
+
+One "step" = one fused control step (reference chunk -> SQP-RTI solve -> first input -> nominal
+prediction -> drag estimate -> 3 RGP updates) for every quadrotor of the batch, followed by the
+on-device drag plant that produces the next measurement (closed loop, no host traffic: all inputs
+are resident in HBM when the timed region starts).  Workload at N GPUs: BASELINE configs[1]
+per GPU (1024 hummingbirds, horizon N=20, 10 RGP basis points per axis) on seeded random-waypoint
+trajectories; instances are sharded by global index, no collective on the data path, one RCCL
+all-reduce of the 5-number tracking statistic at the end (weak scaling).
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mpc_quad_ros_amd.engine import Engine  # noqa: E402
+from mpc_quad_ros_amd.params import PRECISION_F32, PRECISION_F64, EngineConfig, hummingbird, rgp_basis_linspace  # noqa: E402
+from mpc_quad_ros_amd.trajectories import swarm_trajectories  # noqa: E402
+
+X0 = np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP_VECTOR_PEAK = {"f64": 78.6, "f32": 157.3}   # TFLOP/s (matrix = vector rate for these dtypes on gfx950)
+
+
+def algorithmic_bytes(N, nb, itemsize):
+    """floats(N,nb) = 13N + 2(17N+13) + 6nb + 6nb^2 + 45 per quad per step."""
+    return itemsize * (13 * N + 2 * (17 * N + 13) + 6 * nb + 6 * nb * nb + 45)
+
+
+def algorithmic_flops(N, nb, ipm_it):
+    """Dense counts of the implemented algorithm per quad per step:
+    shooting N*(4*(2*60*14) + 4*(150+30*nb)), Riccati factorisation per IPM/polish pass
+    N*2*(13*13*17 + 153*13 + 52*4 + 91*4), vector sweeps 4*N*2*(17*13+4*13), RGP 3*8*nb^2."""
+    shoot = N * (4 * 2 * 60 * 14 + 4 * (150 + 30 * nb))
+    fact = N * 2 * (13 * 13 * 17 + 153 * 13 + 52 * 4 + 91 * 4)
+    vec = 4 * N * 2 * (17 * 13 + 4 * 13)
+    return shoot + ipm_it * (fact + vec) + 24 * nb * nb
+
+
+def make_engine(B, N, nb, precision, device, first_index, seed):
+    cfg = EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb),
+                       theta=[1.0, 0.1, 0.1], dt_pred=0.01, device=device, precision=precision)
+    e = Engine(cfg)
+    traj, lens = swarm_trajectories(seed, first_index, B, v_max=12.0, a_max=12.0)
+    e.set_trajectories(traj, lens)
+    e.sim_reset(np.tile(X0, (B, 1)))
+    return e, cfg
+
+
+def cpu_baseline(N, nb, seed, budget_s=15.0):
+    """The fp64 CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload, all
+    host cores via OpenMP.  Reported next to the GPU number; not the thing measured or shipped."""
+    from oracle.oracle import OracleEngine
+    cores = os.cpu_count() or 1
+    try:
+        native = True
+        OracleEngine(EngineConfig(batch=1, N=5), native=True).close()
+    except Exception:
+        native = False
+    B = 16 * cores
+    cfg = EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb),
+                       theta=[1.0, 0.1, 0.1], dt_pred=0.01)
+    o = OracleEngine(cfg, native=native)
+    traj, lens = swarm_trajectories(seed, 0, B)
+    o.set_trajectories(traj, lens)
+    x = np.tile(X0, (B, 1))
+    for _ in range(2):
+        w, _ = o.step(x)
+        x = o.plant_update(x, w, 5e-3)
+    steps, t_step = 0, 0.0
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and steps < 200:
+        t0 = time.perf_counter()
+        w, _ = o.step(x)
+        t_step += time.perf_counter() - t0
+        x = o.plant_update(o.plant_update(x, w, 5e-3), w, 5e-3)
+        steps += 1
+    return {"value": B * steps / t_step, "unit": "control steps/s", "cores": cores, "kind": "port",
+            "sample": f"{B} quads x {steps} closed-loop steps, N={N} nb={nb}, fp64 C++ oracle (dense condensing + IPM), "
+                      f"OpenMP {cores} threads, {'-march=native' if native else 'generic'} build",
+            "us_per_step_per_core": 1e6 * t_step * cores / (B * steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="quadrotors per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--nb", type=int, default=10)
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # host-side rendezvous only (barrier, max, id broadcast)
+        dist.init_process_group("gloo", init_method="env://")
+    if world != args.gpus and rank == 0:
+        print(f"# note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+
+    B, N, nb = args.batch, args.horizon, args.nb
+    prec = PRECISION_F64 if args.precision == "f64" else PRECISION_F32
+    itemsize = 8 if prec == PRECISION_F64 else 4
+    e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed)
+    if world > 1:
+        import torch
+        uid = [e.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        e.comm_init(rank, world, uid[0])
+
+    def barrier():
+        e.lib.mpcq_synchronize(e.h)          # hipStreamSynchronize on the engine's stream (the only one used)
+        if dist is not None:
+            dist.barrier()
+
+    n_sub = 2                                # 100 Hz odometry = 2 plant substeps of 5 ms
+    e.sim_steps(args.warmup, n_sub, 5e-3)
+    barrier()
+    t0 = time.perf_counter()
+    e.sim_steps(args.steps, n_sub, 5e-3)     # K fused steps + plant, back-to-back on one stream
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    ktime, klaunch = e.get_kernel_time()     # HIP events around every step_kernel launch of the timed region
+    its = e.get_qp_iter()
+    status = e.get_status()
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    stats = e.allreduce_tracking_stats() if world > 1 else e.get_tracking_stats()
+
+    if rank == 0:
+        total_steps = B * world * args.steps
+        value = total_steps / elapsed
+        k_avg = ktime / max(klaunch, 1)
+        bytes_launch = algorithmic_bytes(N, nb, itemsize) * B
+        achieved = bytes_launch / k_avg / 1e9
+        flops_launch = algorithmic_flops(N, nb, float(its.mean())) * B
+        out = {
+            "metric": "batched MPC+RGP control steps/sec (N=20 horizon)" if N == 20 else f"batched MPC+RGP control steps/sec (N={N} horizon)",
+            "value": value, "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1] per GPU: batch {B} hummingbird quadrotors, N={N}, RGP {nb} basis pts/axis, "
+                                   "closed loop with on-device drag plant, seeded random-waypoint references (v_max=a_max=12)",
+                       "batch_per_gpu": B, "global_batch": B * world, "horizon_nodes": N, "rgp_basis": nb,
+                       "parallelism": f"shard{world}" if world > 1 else "single", "threads_per_quad": e_threads()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": f"mpcq::step_kernel<{'double' if prec == PRECISION_F64 else 'float'}>",
+                         "kernel_avg_ms": 1e3 * k_avg, "kernel_launches": klaunch,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "path is latency/VALU/LDS bound, not HBM bound (DESIGN.md): secondary figure below",
+                         "vector_flops": {"achieved_tflops": flops_launch / k_avg / 1e12,
+                                          "peak_tflops": FP_VECTOR_PEAK[args.precision],
+                                          "frac": flops_launch / k_avg / 1e12 / FP_VECTOR_PEAK[args.precision]}},
+            "solver": {"mean_ipm_plus_polish_passes": float(its.mean()), "max": int(its.max()), "failed": int((status != 0).sum())},
+            "tracking": {"rms_pos_m": float(np.sqrt(stats[0] / (3 * max(stats[2], 1)))), "steps": float(stats[2]),
+                         "max_pos_err_m": float(np.sqrt(stats[3])), "failed_instances": float(stats[4])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, nb, args.seed)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def e_threads():
+    t = os.environ.get("MPCQ_THREADS", "64")
+    return int(t) if t in ("64", "128", "256") else 64
+
+
+if __name__ == "__main__":
+    main()

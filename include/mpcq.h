@@ -133,6 +133,9 @@ void* mpcq_stream(mpcq_engine* e);   /* hipStream_t the engine launches on */
 int mpcq_sim_reset(mpcq_engine* e, const double* x0);
 int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt);
 int mpcq_sim_get_state(mpcq_engine* e, double* x /*[B,13]*/, double* w /*[B,4] or NULL*/);
+/* HIP-event time of the step-kernel launches of the last mpcq_sim_steps call (events recorded on
+ * the engine's stream around every launch): total seconds and number of launches. */
+int mpcq_get_kernel_time(mpcq_engine* e, double* seconds, int32_t* launches);
 
 /* ---- tracking statistic (src/Visualiser.py:787-789,809-811,918), summed over this engine's
  * instances since the last reset: out[0]=sum |e_pos|^2, out[1]=sum |e_vel|^2, out[2]=steps,

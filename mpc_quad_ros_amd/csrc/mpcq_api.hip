@@ -102,6 +102,9 @@ struct mpcq_engine {
   void* comm = nullptr;
   int nranks = 1;
   double* d_stats5 = nullptr;
+  std::vector<hipEvent_t> kev;   // per-launch event pairs of the last sim_steps call
+  double ktime = 0;
+  int klaunches = 0;
   virtual int init() = 0;
   virtual int reset() = 0;
   virtual int set_trajectories(const double*, const int32_t*, int32_t) = 0;
@@ -146,6 +149,7 @@ struct EngineT : mpcq_engine {
       if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    for (hipEvent_t ev : kev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
     if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
   }
@@ -393,15 +397,25 @@ struct EngineT : mpcq_engine {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_sim_steps needs mpcq_set_trajectories first");
     mpcq::DevState<T> s2 = st;
     s2.x_meas = d_xs;
+    while ((int)kev.size() < 2 * K) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
     HIP_TRY(hipEventRecord(ev0, stream));
     for (int k = 0; k < K; ++k) {
+      HIP_TRY(hipEventRecord(kev[2 * k], stream));
       hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+      HIP_TRY(hipEventRecord(kev[2 * k + 1], stream));
       hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, (T)sim_dt, B);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
     HIP_TRY(hipStreamSynchronize(stream));
+    ktime = 0;
+    klaunches = K;
+    for (int k = 0; k < K; ++k) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, kev[2 * k], kev[2 * k + 1]));
+      ktime += ms * 1e-3;
+    }
     return 0;
   }
   int sim_get(double* x, double* w) override {
@@ -512,6 +526,7 @@ void* mpcq_stream(mpcq_engine* e) { return e ? (void*)e->stream : nullptr; }
 int mpcq_sim_reset(mpcq_engine* e, const double* x0) { CHK(e); return e->sim_reset(x0); }
 int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { CHK(e); return e->sim_steps(K, n_sub, sim_dt); }
 int mpcq_sim_get_state(mpcq_engine* e, double* x, double* w) { CHK(e); return e->sim_get(x, w); }
+int mpcq_get_kernel_time(mpcq_engine* e, double* s, int32_t* n) { CHK(e); if (s) *s = e->ktime; if (n) *n = e->klaunches; return 0; }
 int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]) { CHK(e); return e->stats(out); }
 
 int mpcq_comm_unique_id(void* id128) {

@@ -152,6 +152,12 @@ class Engine:
         self._check(self.lib.mpcq_sim_get_state(self.h, _lib.d(x), _lib.d(w)))
         return x, w
 
+    def get_kernel_time(self):
+        t = ctypes.c_double()
+        n = ctypes.c_int32()
+        self._check(self.lib.mpcq_get_kernel_time(self.h, ctypes.byref(t), ctypes.byref(n)))
+        return t.value, n.value
+
     def get_tracking_stats(self):
         out = np.zeros(5)
         self._check(self.lib.mpcq_get_tracking_stats(self.h, _lib.d(out)))
