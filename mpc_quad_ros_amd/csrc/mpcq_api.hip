@@ -136,8 +136,9 @@ struct EngineT : mpcq_engine {
   mpcq::DevState<T> st;
   mpcq::Lds L;
   size_t lds_bytes = 0;
-  T *d_basis = nullptr, *d_Kxinv = nullptr, *d_Kx = nullptr, *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr;
-  T *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
+  std::vector<double> hbufd;
+  T *d_basis = nullptr, *d_Kxinv = nullptr, *d_Kx = nullptr;
+  double *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr, *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
   int* d_tlen = nullptr;
   std::vector<T> hbuf;
   std::vector<double> Kx;
@@ -159,14 +160,24 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(*p), stream));
     return 0;
   }
-  int h2d(T* dst, const double* src, size_t n) {
+  int h2q(T* dst, const double* src, size_t n) {
     hbuf.resize(n);
     for (size_t i = 0; i < n; ++i) hbuf[i] = (T)src[i];
     HIP_TRY(hipMemcpyAsync(dst, hbuf.data(), n * sizeof(T), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
-  int d2h(double* dst, const T* src, size_t n) {
+  int h2d(double* dst, const double* src, size_t n) {
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int d2h(double* dst, const double* src, size_t n) {
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int q2h(double* dst, const T* src, size_t n) {
     hbuf.resize(n);
     HIP_TRY(hipMemcpyAsync(hbuf.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -180,7 +191,6 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
-    if (const char* t = getenv("MPCQ_THREADS")) { int v = atoi(t); if (v == 64 || v == 128 || v == 256) threads = v; }
     std::memset(&m, 0, sizeof(m));
     std::memset(&st, 0, sizeof(st));
     m.N = N; m.nb = nb; m.skip = c.skip; m.Tmax = 0; m.B = B;
@@ -193,15 +203,15 @@ struct EngineT : mpcq_engine {
     if (const char* t = getenv("MPCQ_IPM_TOL")) m.ipm_tol = (T)atof(t);
     if (const char* t = getenv("MPCQ_POLISH_MAX")) m.polish_max = atoi(t);
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;
-    m.h = (T)(c.T / c.N); m.dt_pred = (T)c.dt_pred;
-    m.mass = (T)c.mass; m.tmax = (T)c.max_thrust; m.g = (T)c.g; m.aero_drag = (T)c.aero_drag;
-    for (int i = 0; i < 3; ++i) { m.J[i] = (T)c.J[i]; m.rotor_drag[i] = (T)c.rotor_drag[i]; }
+    m.h = c.T / c.N; m.dt_pred = c.dt_pred;
+    m.mass = c.mass; m.tmax = c.max_thrust; m.g = c.g; m.aero_drag = c.aero_drag;
+    for (int i = 0; i < 3; ++i) { m.J[i] = c.J[i]; m.rotor_drag[i] = c.rotor_drag[i]; }
     for (int i = 0; i < 4; ++i) {
-      m.xf[i] = (T)c.x_f[i]; m.yf[i] = (T)c.y_f[i]; m.zl[i] = (T)c.z_l_tau[i];
-      m.ulb[i] = (T)c.u_lb[i]; m.uub[i] = (T)c.u_ub[i]; m.uref[i] = (T)c.u_ref[i];
+      m.xf[i] = c.x_f[i]; m.yf[i] = c.y_f[i]; m.zl[i] = c.z_l_tau[i];
+      m.ulb[i] = c.u_lb[i]; m.uub[i] = c.u_ub[i]; m.uref[i] = c.u_ref[i];
     }
-    for (int i = 0; i < 17; ++i) m.W[i] = (T)c.W[i];
-    for (int i = 0; i < 13; ++i) m.We[i] = (T)c.W_e[i];
+    for (int i = 0; i < 17; ++i) m.W[i] = c.W[i];
+    for (int i = 0; i < 13; ++i) m.We[i] = c.W_e[i];
     // RGP constants: K_x = K(X,X) + sn^2 I and its inverse (RGP.__init__, src/gp/RGP.py:140-157)
     Kx.assign((size_t)3 * nb * nb, 0.0);
     std::vector<double> Kxinv((size_t)3 * nb * nb, 0.0);
@@ -224,9 +234,9 @@ struct EngineT : mpcq_engine {
     if ((rc = dalloc(d_Kxinv, (size_t)3 * nb * nb))) return rc;
     if ((rc = dalloc(d_Kx, (size_t)3 * nb * nb))) return rc;
     if (nb) {
-      if ((rc = h2d(d_basis, basis.data(), 3 * nb))) return rc;
-      if ((rc = h2d(d_Kxinv, Kxinv.data(), (size_t)3 * nb * nb))) return rc;
-      if ((rc = h2d(d_Kx, Kx.data(), (size_t)3 * nb * nb))) return rc;
+      if ((rc = h2q(d_basis, basis.data(), 3 * nb))) return rc;
+      if ((rc = h2q(d_Kxinv, Kxinv.data(), (size_t)3 * nb * nb))) return rc;
+      if ((rc = h2q(d_Kx, Kx.data(), (size_t)3 * nb * nb))) return rc;
     }
     m.basis = d_basis; m.Kxinv = d_Kxinv;
     const size_t Bz = B;
@@ -255,7 +265,7 @@ struct EngineT : mpcq_engine {
     if ((rc = dalloc(d_stats5, 8))) return rc;
     st.tlen = d_tlen; st.traj = nullptr; st.x_meas = d_xin;
     L = mpcq::lds_layout(N, nb);
-    lds_bytes = (size_t)L.total * sizeof(T);
+    lds_bytes = mpcq::lds_bytes<T>(L);
     if (lds_bytes > 160 * 1024) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS (N/nb too large for this precision)");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::step_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::regress_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -264,11 +274,11 @@ struct EngineT : mpcq_engine {
 
   int reset() override {
     const size_t Bz = B;
-    HIP_TRY(hipMemsetAsync(st.X, 0, Bz * (N + 1) * 13 * sizeof(T), stream));
-    HIP_TRY(hipMemsetAsync(st.U, 0, Bz * N * 4 * sizeof(T), stream));
+    HIP_TRY(hipMemsetAsync(st.X, 0, Bz * (N + 1) * 13 * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(st.U, 0, Bz * N * 4 * sizeof(double), stream));
     if (nb) HIP_TRY(hipMemsetAsync(st.mu, 0, Bz * 3 * nb * sizeof(T), stream));
-    HIP_TRY(hipMemsetAsync(st.xpp, 0, Bz * 13 * sizeof(T), stream));
-    HIP_TRY(hipMemsetAsync(st.stats, 0, Bz * 4 * sizeof(T), stream));
+    HIP_TRY(hipMemsetAsync(st.xpp, 0, Bz * 13 * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(st.stats, 0, Bz * 4 * sizeof(double), stream));
     HIP_TRY(hipMemsetAsync(st.has_prev, 0, Bz * sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(st.idx, 0, Bz * sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(st.status, 0, Bz * sizeof(int), stream));
@@ -289,7 +299,7 @@ struct EngineT : mpcq_engine {
     for (int b = 0; b < B; ++b)
       if (len[b] <= 0 || len[b] > Tmax) return fail(MPCQ_ERR_INVALID, "trajectory length out of range");
     if (d_traj && m.Tmax != Tmax) { (void)hipFree(d_traj); d_traj = nullptr; }
-    if (!d_traj) HIP_TRY(hipMalloc((void**)&d_traj, (size_t)B * Tmax * 13 * sizeof(T)));
+    if (!d_traj) HIP_TRY(hipMalloc((void**)&d_traj, (size_t)B * Tmax * 13 * sizeof(double)));
     m.Tmax = Tmax;
     int rc;
     if ((rc = h2d(d_traj, traj, (size_t)B * Tmax * 13))) return rc;
@@ -305,11 +315,11 @@ struct EngineT : mpcq_engine {
     if ((rc = h2d(st.yref, yref, (size_t)B * N * 17))) return rc;
     return h2d(st.yrefN, yrefN, (size_t)B * 13);
   }
-  int set_params(const double* mu) override { return nb ? h2d(st.mu, mu, (size_t)B * 3 * nb) : 0; }
+  int set_params(const double* mu) override { return nb ? h2q(st.mu, mu, (size_t)B * 3 * nb) : 0; }
 
   int launch_step(int mode) {
     HIP_TRY(hipEventRecord(ev0, stream));
-    hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, st, mode);
+    hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(64), lds_bytes, stream, m, st, mode);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
@@ -350,7 +360,7 @@ struct EngineT : mpcq_engine {
     int rc;
     if ((rc = h2d(d_xin, x, (size_t)B * 13))) return rc;
     if ((rc = h2d(d_uin, u, (size_t)B * 4))) return rc;
-    hipLaunchKernelGGL(mpcq::predict_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xin, d_uin, (T)dt, d_tmp, B);
+    hipLaunchKernelGGL(mpcq::predict_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xin, d_uin, dt, d_tmp, B);
     HIP_TRY(hipGetLastError());
     return d2h(out, d_tmp, (size_t)B * 13);
   }
@@ -359,15 +369,15 @@ struct EngineT : mpcq_engine {
     int rc;
     if ((rc = h2d(d_vb, vb, (size_t)B * 3))) return rc;
     if ((rc = h2d(d_ad, ad, (size_t)B * 3))) return rc;
-    hipLaunchKernelGGL(mpcq::regress_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, st, d_vb, d_ad);
+    hipLaunchKernelGGL(mpcq::regress_kernel<T>, dim3(B), dim3(64), lds_bytes, stream, m, st, d_vb, d_ad);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
   int get_rgp(double* mu, double* C) override {
     int rc;
-    if (mu && nb && (rc = d2h(mu, st.mu, (size_t)B * 3 * nb))) return rc;
-    if (C && nb && (rc = d2h(C, st.C, (size_t)B * 3 * nb * nb))) return rc;
+    if (mu && nb && (rc = q2h(mu, st.mu, (size_t)B * 3 * nb))) return rc;
+    if (C && nb && (rc = q2h(C, st.C, (size_t)B * 3 * nb * nb))) return rc;
     return 0;
   }
   int step(const double* x_meas, double* w_out, double* x_pred_out) override {
@@ -383,10 +393,10 @@ struct EngineT : mpcq_engine {
   int step_device(const void* d_x, void* d_w) override {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_step_device_async needs mpcq_set_trajectories first");
     mpcq::DevState<T> s2 = st;
-    s2.x_meas = (const T*)d_x;
-    if (d_w) s2.w = (T*)d_w;
+    s2.x_meas = (const double*)d_x;
+    if (d_w) s2.w = (double*)d_w;
     HIP_TRY(hipEventRecord(ev0, stream));
-    hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+    hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
@@ -401,9 +411,9 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipEventRecord(ev0, stream));
     for (int k = 0; k < K; ++k) {
       HIP_TRY(hipEventRecord(kev[2 * k], stream));
-      hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(threads), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+      hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
       HIP_TRY(hipEventRecord(kev[2 * k + 1], stream));
-      hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, (T)sim_dt, B);
+      hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, sim_dt, B);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
@@ -425,7 +435,7 @@ struct EngineT : mpcq_engine {
     return 0;
   }
   int stats(double* out5) override {
-    hipLaunchKernelGGL(mpcq::stats_kernel<T>, dim3(1), dim3(256), 5 * 256 * sizeof(double), stream, st.stats, st.status, B, d_stats5);
+    hipLaunchKernelGGL(mpcq::stats_kernel, dim3(1), dim3(256), 5 * 256 * sizeof(double), stream, st.stats, st.status, B, d_stats5);
     HIP_TRY(hipGetLastError());
     if (out5) {
       HIP_TRY(hipMemcpyAsync(out5, d_stats5, 5 * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -437,8 +447,8 @@ struct EngineT : mpcq_engine {
     int rc;
     if (X && (rc = d2h(X, st.X, (size_t)B * (N + 1) * 13))) return rc;
     if (U && (rc = d2h(U, st.U, (size_t)B * N * 4))) return rc;
-    if (mu && nb && (rc = d2h(mu, st.mu, (size_t)B * 3 * nb))) return rc;
-    if (C && nb && (rc = d2h(C, st.C, (size_t)B * 3 * nb * nb))) return rc;
+    if (mu && nb && (rc = q2h(mu, st.mu, (size_t)B * 3 * nb))) return rc;
+    if (C && nb && (rc = q2h(C, st.C, (size_t)B * 3 * nb * nb))) return rc;
     if (xpp && (rc = d2h(xpp, st.xpp, (size_t)B * 13))) return rc;
     if (hp && (rc = get_int(3, hp))) return rc;
     if (idx && (rc = get_int(2, idx))) return rc;
@@ -449,8 +459,8 @@ struct EngineT : mpcq_engine {
     int rc;
     if (X && (rc = h2d(st.X, X, (size_t)B * (N + 1) * 13))) return rc;
     if (U && (rc = h2d(st.U, U, (size_t)B * N * 4))) return rc;
-    if (mu && nb && (rc = h2d(st.mu, mu, (size_t)B * 3 * nb))) return rc;
-    if (C && nb && (rc = h2d(st.C, C, (size_t)B * 3 * nb * nb))) return rc;
+    if (mu && nb && (rc = h2q(st.mu, mu, (size_t)B * 3 * nb))) return rc;
+    if (C && nb && (rc = h2q(st.C, C, (size_t)B * 3 * nb * nb))) return rc;
     if (xpp && (rc = h2d(st.xpp, xpp, (size_t)B * 13))) return rc;
     if (hp) HIP_TRY(hipMemcpyAsync(st.has_prev, hp, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     if (idx) HIP_TRY(hipMemcpyAsync(st.idx, idx, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));

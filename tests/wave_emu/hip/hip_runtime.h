@@ -58,6 +58,21 @@ template <typename T> inline T __shfl_xor(T v, int mask) {
   return r;
 }
 inline float __expf(float x) { return std::exp(x); }
+inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+template <typename T> inline T __shfl(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shuffle payload");
+  uint64_t* ex = emu::exchange();
+  const unsigned t = emu::cur->tid.x;
+  uint64_t raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  ex[t] = raw;
+  emu::sync();
+  raw = ex[(t & ~63u) | ((unsigned)src & 63u)];
+  emu::sync();
+  T r;
+  std::memcpy(&r, &raw, sizeof(T));
+  return r;
+}
 
 // ---- host runtime subset
 typedef int hipError_t;
