@@ -124,6 +124,7 @@ struct mpcq_engine {
   virtual int sim_steps(int, int, double) = 0;
   virtual int sim_get(double*, double*) = 0;
   virtual int stats(double*) = 0;
+  virtual int get_prof(unsigned long long*) = 0;
   virtual int get_state(double*, double*, double*, double*, double*, int32_t*, int32_t*) = 0;
   virtual int set_state(const double*, const double*, const double*, const double*, const double*, const int32_t*, const int32_t*) = 0;
 };
@@ -263,6 +264,9 @@ struct EngineT : mpcq_engine {
     if ((rc = dalloc(d_vb, Bz * 3))) return rc;
     if ((rc = dalloc(d_ad, Bz * 3))) return rc;
     if ((rc = dalloc(d_stats5, 8))) return rc;
+#ifdef MPCQ_PROFILE
+    if ((rc = dalloc(st.prof, Bz * mpcq::PF_N))) return rc;
+#endif
     st.tlen = d_tlen; st.traj = nullptr; st.x_meas = d_xin;
     L = mpcq::lds_layout(N, nb);
     lds_bytes = mpcq::lds_bytes<T>(L);
@@ -443,6 +447,16 @@ struct EngineT : mpcq_engine {
     }
     return 0;
   }
+  int get_prof(unsigned long long* out) override {
+#ifdef MPCQ_PROFILE
+    HIP_TRY(hipMemcpyAsync(out, st.prof, (size_t)B * mpcq::PF_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+#else
+    (void)out;
+    return fail(MPCQ_ERR_STATE, "built without MPCQ_PROFILE");
+#endif
+  }
   int get_state(double* X, double* U, double* mu, double* C, double* xpp, int32_t* hp, int32_t* idx) override {
     int rc;
     if (X && (rc = d2h(X, st.X, (size_t)B * (N + 1) * 13))) return rc;
@@ -538,6 +552,8 @@ int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { CH
 int mpcq_sim_get_state(mpcq_engine* e, double* x, double* w) { CHK(e); return e->sim_get(x, w); }
 int mpcq_get_kernel_time(mpcq_engine* e, double* s, int32_t* n) { CHK(e); if (s) *s = e->ktime; if (n) *n = e->klaunches; return 0; }
 int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]) { CHK(e); return e->stats(out); }
+/* diagnostic build only: per-instance phase cycle totals of the last step, [B][16] */
+int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out) { CHK(e); return e->get_prof(out); }
 
 int mpcq_comm_unique_id(void* id128) {
   int rc = rccl_load();

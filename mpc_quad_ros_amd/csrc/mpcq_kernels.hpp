@@ -30,9 +30,27 @@ constexpr int NX = 13, NU = 4, NY = 17;
 constexpr int ABW = 16;          // row stride of AB' = columns 3..16 of [A|B] (cols 0..2 of A are [I;0])
 constexpr int ABS = NX * ABW;    // per-stage stride of AB'
 constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded to 16)
-constexpr int SUBW = 40;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
+constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
+constexpr int SUBS = 4 * SUBW + 1;  // per-stage stride of the records (odd: lanes of different stages hit different banks)
 
 enum : int { MODE_TRAJ = 1, MODE_POST = 2 };
+
+// Diagnostic build only (-DMPCQ_PROFILE, libmpcq_prof.so): per-phase shader-cycle totals per instance.
+enum : int { PF_LOAD = 0, PF_SHOOT_X, PF_SHOOT_S, PF_FACTOR, PF_FWD, PF_BWD, PF_ADJ, PF_ROLL, PF_ELEM, PF_POST, PF_TOTAL, PF_N = 16 };
+#ifdef MPCQ_PROFILE
+struct Prof { unsigned long long acc[PF_N]; unsigned long long t; };
+__device__ inline void pf_start(Prof& p) { p.t = __builtin_readcyclecounter(); }
+__device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __builtin_readcyclecounter(); p.acc[k] += n - p.t; p.t = n; }
+#define PF_ARG , Prof& pf
+#define PF_PASS , pf
+#define PF_START() pf_start(pf)
+#define PF_STOP(k) pf_stop(pf, k)
+#else
+#define PF_ARG
+#define PF_PASS
+#define PF_START()
+#define PF_STOP(k)
+#endif
 
 template <typename TQ>
 struct DevModel {
@@ -69,6 +87,7 @@ struct DevState {
   const int* tlen;
   int* status;
   int* qp_iter;
+  unsigned long long* prof;   // [B][PF_N] (diagnostic build only)
 };
 
 // ------------------------------------------------------------------ LDS layout
@@ -77,7 +96,7 @@ struct DevState {
 struct Lds {
   int X, U, x0, dbytes;
   int AB, c, qv, r0, lb, ub, alpha, basis;
-  int z, sl, su, ll, lu, grad, dza, dz, rho, kv, act, dx, Dx, K, Linv, P, T1, F;
+  int z, sl, su, ll, lu, grad, dza, dz, rho, kv, act, rt, dx, Dx, K, Linv, P, T1, F;
   int sub, rgp, qtotal;
 };
 __host__ __device__ inline int al4(int v) { return (v + 3) & ~3; }
@@ -99,9 +118,9 @@ __host__ __device__ inline Lds lds_layout(int N, int nb) {
   L.basis = take(3 * nb);
   const int u0 = o;  // ---- union: shooting records | QP workspace | RGP workspace
   L.sub = u0;
-  const int sub_end = u0 + al4(N * 4 * SUBW);
+  const int sub_end = u0 + al4(N * SUBS);
   L.z = take(nv); L.sl = take(nv); L.su = take(nv); L.ll = take(nv); L.lu = take(nv);
-  L.grad = take(nv); L.dza = take(nv); L.dz = take(nv); L.rho = take(nv); L.kv = take(nv); L.act = take(nv);
+  L.grad = take(nv); L.dza = take(nv); L.dz = take(nv); L.rho = take(nv); L.kv = take(nv); L.act = take(nv); L.rt = take(nv);
   L.dx = take((N + 1) * NX);
   L.Dx = take((N + 1) * NX);
   L.K = take(N * KS);
@@ -122,27 +141,49 @@ template <typename TQ> __host__ __device__ inline size_t lds_bytes(const Lds& L)
 // ------------------------------------------------------------------ small helpers
 template <typename T> struct alignas(16) V4 { T a, b, c, d; };
 
-template <typename T> __device__ inline T bc(T v, int lane) { return __shfl(v, lane); }  // lane broadcast
-template <typename T> __device__ inline T wave_sum(T v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-template <typename T> __device__ inline T wave_max(T v) {
-  for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o); v = v > w ? v : w; }
-  return v;
-}
-template <typename T> __device__ inline T wave_min(T v) {
-  for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o); v = v < w ? v : w; }
-  return v;
-}
 template <typename T> __device__ inline T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> __device__ inline T tmax(T a, T b) { return a > b ? a : b; }
+
+// lane broadcast: `lane` must be wave-uniform (a constant after unrolling) -> v_readlane_b32 into an SGPR
+__device__ inline int bc(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ inline float bc(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ inline double bc(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// DPP lane permutes inside 16-lane rows (quad_perm / row_ror), no LDS involved
+template <int CTRL> __device__ inline int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ inline float dpp(float v) { return __int_as_float(dpp<CTRL>(__float_as_int(v))); }
+template <int CTRL> __device__ inline double dpp(double v) {
+  return __hiloint2double(dpp<CTRL>(__double2hiint(v)), dpp<CTRL>(__double2loint(v)));
+}
+// wave-wide reductions: butterfly inside each row of 16 with DPP, then the 4 row results through SGPRs
+template <typename T, typename OP> __device__ inline T wave_reduce(T v, OP op) {
+  v = op(v, dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = op(v, dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = op(v, dpp<0x124>(v));   // row_ror:4
+  v = op(v, dpp<0x128>(v));   // row_ror:8
+  return op(op(bc(v, 0), bc(v, 16)), op(bc(v, 32), bc(v, 48)));
+}
+template <typename T> __device__ inline T wave_sum(T v) { return wave_reduce(v, [](T a, T b) { return a + b; }); }
+template <typename T> __device__ inline T wave_max(T v) { return wave_reduce(v, [](T a, T b) { return a > b ? a : b; }); }
+template <typename T> __device__ inline T wave_min(T v) { return wave_reduce(v, [](T a, T b) { return a < b ? a : b; }); }
+__device__ inline float  tdiv(float a, float b)  { return __fdividef(a, b); }   // a * rcp(b): ~1 ulp, QP arithmetic only
+__device__ inline double tdiv(double a, double b) { return a / b; }
 __device__ inline float  texp(float x)  { return __expf(x); }
 __device__ inline double texp(double x) { return exp(x); }
 __device__ inline float  trsqrt(float x)  { return rsqrtf(x); }
 __device__ inline double trsqrt(double x) { return 1.0 / sqrt(x); }
 __device__ inline float  tabs(float x)  { return fabsf(x); }
 __device__ inline double tabs(double x) { return fabs(x); }
+
+// AB' is stored with an XOR swizzle of its 4-float column groups, element (r, c) at
+//   r*ABW + (((c >> 2) ^ sw(r)) << 2) + (c & 3),  sw(r) = (r >> 1) & 3,
+// so that both access directions are (nearly) bank-conflict free: a fixed row read across 14 column
+// lanes stays a permutation of one 16-float row, and a fixed column read across 13 row lanes spreads
+// over 8 banks instead of 2.
+__device__ inline int sw(int r) { return (r >> 1) & 3; }
+__device__ inline int abo(int r, int c) { return r * ABW + ((((c >> 2) ^ sw(r)) << 2) | (c & 3)); }
 
 template <typename T> __device__ inline void rotmat(const T* q, T* R) {
   const T qw = q[0], qx = q[1], qy = q[2], qz = q[3];
@@ -325,7 +366,7 @@ __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* 
 #pragma unroll
     for (int j = 0; j < NU; ++j) u[j] = (TQ)D[L.U + i * NU + j];
     const TQ* al = gp ? S + L.alpha : nullptr;
-    TQ* sub = S + L.sub + i * 4 * SUBW;
+    TQ* sub = S + L.sub + i * SUBS;
     model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, x, u, al, S + L.basis, k, sub);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = x[j] + h / 2 * k[j]; }
@@ -360,13 +401,12 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, const Lds& L) {
 #pragma unroll
     for (int r = 0; r < NX; ++r) { Sp[r] = 0; acc[r] = 0; }
     TQ jur[3] = {0, 0, 0};
-    if (ucol) {
-      const int c = j - NX;
-      jur[0] = qc.tmax * qc.yf[c] / qc.J[0]; jur[1] = -qc.tmax * qc.xf[c] / qc.J[1]; jur[2] = qc.tmax * qc.zl[c] / qc.J[2];
-    }
+#pragma unroll
+    for (int c = 0; c < NU; ++c)
+      if (j - NX == c) { jur[0] = qc.tmax * qc.yf[c] / qc.J[0]; jur[1] = -qc.tmax * qc.xf[c] / qc.J[1]; jur[2] = qc.tmax * qc.zl[c] / qc.J[2]; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const TQ* sub = S + L.sub + (i * 4 + s) * SUBW;
+      const TQ* sub = S + L.sub + i * SUBS + s * SUBW;
       const TQ hs = h * a_s[s];
 #pragma unroll
       for (int r = 0; r < NX; ++r) Z[r] = ((r == j) ? TQ(1) : TQ(0)) + hs * Sp[r];
@@ -395,10 +435,13 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, const Lds& L) {
     }
     TQ* AB = S + L.AB + i * ABS;
 #pragma unroll
-    for (int r = 0; r < NX; ++r) AB[r * ABW + jp] = ((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r];
+    for (int r = 0; r < NX; ++r) AB[abo(r, jp)] = ((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r];
   }
   // zero the two pad columns (read by the vectorised 4-wide loads)
-  for (int it = threadIdx.x; it < N * NX * 2; it += 64) S[L.AB + (it >> 1) * ABW + 14 + (it & 1)] = 0;
+  for (int it = threadIdx.x; it < N * NX * 2; it += 64) {
+    const int row = it >> 1, i = row / NX, r = row - i * NX;
+    S[L.AB + i * ABS + abo(r, 14 + (it & 1))] = 0;
+  }
 }
 
 // ------------------------------------------------------------------ QP: vector sweeps
@@ -406,20 +449,36 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, const Lds& L) {
 // dx_0 = x0 - X_0, lb <= du <= ub.  Q_i = h W_x (i<N) / W_e, R = h W_u diagonal; qv, r0, lb, ub, c prepared by
 // the caller.  Vectors of length 13 live on lanes 0..12, input-sized quantities on lanes 13..16.
 
+// column `col` of a stage's AB' (13 values, one per row k), into registers
+template <typename TQ> __device__ inline void load_col(const TQ* ab, int col, TQ (&o)[NX]) {
+#pragma unroll
+  for (int k = 0; k < NX; ++k) o[k] = ab[abo(k, col)];
+}
+// row r of a stage's AB' (14 values + 2 pads) into registers, logical column order
+template <typename TQ> __device__ inline void load_row(const TQ* ab, int r, TQ (&o)[16]) {
+  const int s = sw(r);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) o[c] = ab[r * ABW + ((((c >> 2) ^ s) << 2) | (c & 3))];
+}
+
 // forward rollout dx_{i+1} = A dx_i + B z_i (+ c_i); dx_0 taken from S[dxo + 0..12]
 template <typename TQ>
 __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, const Lds& L, int dxo, int zo, bool with_c) {
   const int N = m.N, lane = threadIdx.x, r = lane < NX ? lane : 0;
   TQ xr = S[dxo + r];
+  TQ cur[16], nxt[16];
+  load_row(S + L.AB, r, cur);
   for (int i = 0; i < N; ++i) {
-    const TQ* ab = S + L.AB + i * ABS + r * ABW;
+    if (i + 1 < N) load_row(S + L.AB + (i + 1) * ABS, r, nxt);
     TQ t = (with_c ? S[L.c + i * NX + r] : TQ(0)) + (r < 3 ? xr : TQ(0));
 #pragma unroll
-    for (int k = 3; k < NX; ++k) t += ab[k - 3] * bc(xr, k);
+    for (int j = 0; j < NU; ++j) t += cur[10 + j] * S[zo + i * NU + j];
 #pragma unroll
-    for (int j = 0; j < NU; ++j) t += ab[10 + j] * S[zo + i * NU + j];
+    for (int k = 3; k < NX; ++k) t += cur[k - 3] * bc(xr, k);
     xr = t;
     if (lane < NX) S[dxo + (i + 1) * NX + lane] = t;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
   }
   __syncthreads();
 }
@@ -428,18 +487,25 @@ __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, const Lds& L, int d
 template <typename TQ>
 __device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, const Lds& L) {
   const int N = m.N, lane = threadIdx.x;
-  const int a = lane < NY ? lane : 0, col = a >= 3 ? a - 3 : 0;
+  const int a = lane < NY ? lane : 0, col = a >= 3 ? a - 3 : 0, ax = a < NX ? a : 0, au = a >= NX ? a - NX : 0;
   const TQ qd = a < NX ? (TQ)(m.h * m.W[a]) : TQ(0), qe = a < NX ? (TQ)m.We[a] : TQ(0);
   const TQ rd = (a >= NX) ? (TQ)(m.h * m.W[a]) : TQ(0);
   TQ pi = a < NX ? qe * S[L.dx + N * NX + a] + S[L.qv + N * NX + a] : TQ(0);
+  TQ cur[NX], nxt[NX];
+  load_col(S + L.AB + (N - 1) * ABS, col, cur);
   for (int i = N - 1; i >= 0; --i) {
-    const TQ* ab = S + L.AB + i * ABS + col;
+    if (i > 0) load_col(S + L.AB + (i - 1) * ABS, col, nxt);
+    const TQ add = a < NX ? qd * S[L.dx + i * NX + ax] + S[L.qv + i * NX + ax]
+                          : rd * S[L.z + i * NU + au] + S[L.r0 + i * NU + au];
     TQ t = 0;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) t += ab[k * ABW] * bc(pi, k);
+    for (int k = 0; k < NX; ++k) t += cur[k] * bc(pi, k);
     if (a < 3) t = pi;
-    if (a < NX) pi = t + qd * S[L.dx + i * NX + a] + S[L.qv + i * NX + a];
-    else if (lane < NY) S[L.grad + i * NU + a - NX] = t + rd * S[L.z + i * NU + a - NX] + S[L.r0 + i * NU + a - NX];
+    t += add;
+    if (lane < NX) pi = t;
+    else if (lane < NY) S[L.grad + i * NU + au] = t;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) cur[k] = nxt[k];
   }
   __syncthreads();
 }
@@ -450,21 +516,27 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, const 
   const int N = m.N, lane = threadIdx.x;
   const int a = lane < NY ? lane : 0, col = a >= 3 ? a - 3 : 0, j = a >= NX ? a - NX : 0, b = a < NX ? a : 0;
   TQ pv = 0;
+  TQ cur[NX], nxt[NX];
+  load_col(S + L.AB + (N - 1) * ABS, col, cur);
   for (int i = N - 1; i >= 0; --i) {
-    const TQ* ab = S + L.AB + i * ABS + col;
+    if (i > 0) load_col(S + L.AB + (i - 1) * ABS, col, nxt);
+    // per-lane coefficients of the second half: K[:,b] for lanes < 13, Linv[j][:] for lanes 13..16
+    const TQ* cf = lane < NX ? S + L.K + i * KS + b : S + L.Linv + i * 16 + j * 4;
+    const int cs = lane < NX ? ABW : 1;
+    const TQ c0 = cf[0], c1 = cf[cs], c2 = cf[2 * cs], c3 = cf[3 * cs];
+    const TQ rho = S[L.rho + i * NU + j];
     TQ t = 0;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) t += ab[k * ABW] * bc(pv, k);
+    for (int k = 0; k < NX; ++k) t += cur[k] * bc(pv, k);
     if (a < 3) t = pv;
-    TQ gt = (a >= NX) ? S[L.rho + i * NU + j] + t : TQ(0);
+    TQ gt = (a >= NX) ? rho + t : TQ(0);
     if (polish && a >= NX && S[L.act + i * NU + j] != TQ(0)) gt = 0;
     const TQ g0 = bc(gt, 13), g1 = bc(gt, 14), g2 = bc(gt, 15), g3 = bc(gt, 16);
-    const TQ* Kc = S + L.K + i * KS + b;
-    pv = lane < NX ? t + Kc[0] * g0 + Kc[ABW] * g1 + Kc[2 * ABW] * g2 + Kc[3 * ABW] * g3 : TQ(0);
-    if (a >= NX && lane < NY) {
-      const TQ* Li = S + L.Linv + i * 16 + j * 4;
-      S[L.kv + i * NU + j] = -(Li[0] * g0 + Li[1] * g1 + Li[2] * g2 + Li[3] * g3);
-    }
+    const TQ comb = c0 * g0 + c1 * g1 + c2 * g2 + c3 * g3;
+    pv = lane < NX ? t + comb : TQ(0);
+    if (a >= NX && lane < NY) S[L.kv + i * NU + j] = -comb;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) cur[k] = nxt[k];
   }
   __syncthreads();
 }
@@ -476,22 +548,41 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& 
   const int r = lane < NX ? lane : 0, j = (lane >= NX && lane < NY) ? lane - NX : 0;
   TQ xr = 0;
   if (lane < NX) S[L.Dx + lane] = 0;
+  // per-lane coefficient row over x_0..x_12: lanes < 13 -> row r of A (identity columns 0..2, then AB' cols 0..9),
+  // lanes 13..16 -> row j of K
+  TQ cur[NX], nxt[NX], bcur[NU], bnxt[NU];
+  auto load = [&](int i, TQ (&cx)[NX], TQ (&cb)[NU]) {
+    if (lane < NX) {
+      TQ row[16];
+      load_row(S + L.AB + i * ABS, r, row);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cx[k] = lane == k ? TQ(1) : TQ(0);
+#pragma unroll
+      for (int k = 3; k < NX; ++k) cx[k] = row[k - 3];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) cb[k] = row[10 + k];
+    } else {
+      const TQ* kr = S + L.K + i * KS + j * ABW;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) cx[k] = kr[k];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) cb[k] = 0;
+    }
+  };
+  load(0, cur, bcur);
   for (int i = 0; i < N; ++i) {
-    // one coefficient row per lane: row r of [A|B]' for lanes < 13, row j of K for lanes 13..16
-    const TQ* row = lane < NX ? S + L.AB + i * ABS + r * ABW - 3 : S + L.K + i * KS + j * ABW;
+    if (i + 1 < N) load(i + 1, nxt, bnxt);
     TQ t = lane < NX ? TQ(0) : S[L.kv + i * NU + j];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const TQ xb = bc(xr, k);
-      t += lane < NX ? (lane == k ? xb : TQ(0)) : row[k] * xb;
-    }
-#pragma unroll
-    for (int k = 3; k < NX; ++k) t += row[k] * bc(xr, k);
+    for (int k = 0; k < NX; ++k) t += cur[k] * bc(xr, k);
     const TQ d0 = bc(t, 13), d1 = bc(t, 14), d2 = bc(t, 15), d3 = bc(t, 16);
     if (lane >= NX && lane < NY) S[dzo + i * NU + j] = t;
-    const TQ* ab = S + L.AB + i * ABS + r * ABW + 10;
-    xr = lane < NX ? t + ab[0] * d0 + ab[1] * d1 + ab[2] * d2 + ab[3] * d3 : TQ(0);
+    xr = lane < NX ? t + bcur[0] * d0 + bcur[1] * d1 + bcur[2] * d2 + bcur[3] * d3 : TQ(0);
     if (lane < NX) S[L.Dx + (i + 1) * NX + lane] = xr;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) cur[k] = nxt[k];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) bcur[k] = bnxt[k];
   }
   __syncthreads();
 }
@@ -504,7 +595,7 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& 
 // Returns false if a stage Hessian was not positive definite.
 template <typename TQ>
 __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L, bool polish) {
-  const int N = m.N, lane = threadIdx.x;
+  const int N = m.N, lane = threadIdx.x, nv = N * NU;
   // ---- per-lane roles, fixed over the sweep
   const int r4 = lane >> 2, g4 = lane & 3;                       // Ph1/Ph4: (row, 4-column group), lanes 0..51
   int fa = 0, fg = 0;                                            // Ph2: lane -> (a', g) with 4g <= a' (32 items)
@@ -538,29 +629,46 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
     for (int j = 0; j < 4; ++j) m3off[j] = b < 3 ? L.T1 + b * ABW + 10 + j : L.F + (10 + j) * ABW + (b - 3);
   }
   const TQ qdiag = r4 < NX ? (TQ)(m.h * m.W[r4]) : TQ(0);
-  // P_N = W_e
+  // stage input Hessian diagonals R~ (negative value = input pinned by the polish)
+  for (int i = lane; i < nv; i += 64) {
+    const TQ rr = (TQ)(m.h * m.W[NX + (i & 3)]);
+    TQ v;
+    if (!polish) v = rr + tdiv(S[L.ll + i], S[L.sl + i]) + tdiv(S[L.lu + i], S[L.su + i]);
+    else v = S[L.act + i] != TQ(0) ? TQ(-1) : rr;
+    S[L.rt + i] = v;
+  }
+  // P_N = W_e ; K pads
   for (int it = lane; it < ABS; it += 64) S[L.P + it] = ((it >> 4) == (it & 15) && (it >> 4) < NX) ? (TQ)m.We[it >> 4] : TQ(0);
+  for (int it = lane; it < N * NU * 3; it += 64) S[L.K + (it / 3) * ABW + NX + it % 3] = 0;
   TQ pv = 0;
+  TQ vc[NX], vn[NX];
+  load_col(S + L.AB + (N - 1) * ABS, vcol, vc);
   __syncthreads();
   for (int i = N - 1; i >= 0; --i) {
     const int pc = (N - 1 - i) & 1;
     const TQ* AB = S + L.AB + i * ABS;
     const TQ* Pn = S + L.P + pc * ABS;
+    if (i > 0) load_col(S + L.AB + (i - 1) * ABS, vcol, vn);
     // ---- Ph1: T1' = P_{i+1} AB'   (13 x 14, 4 columns per lane) ; vector t = [A B]^T p_{i+1}
     if (lane < 52) {
+      TQ prow[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const V4<TQ> v = *reinterpret_cast<const V4<TQ>*>(Pn + r4 * ABW + 4 * q);
+        prow[4 * q] = v.a; prow[4 * q + 1] = v.b; prow[4 * q + 2] = v.c; prow[4 * q + 3] = v.d;
+      }
       TQ a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
       for (int k = 0; k < NX; ++k) {
-        const TQ p = Pn[r4 * ABW + k];
-        const V4<TQ> v = *reinterpret_cast<const V4<TQ>*>(AB + k * ABW + 4 * g4);
-        a0 += p * v.a; a1 += p * v.b; a2 += p * v.c; a3 += p * v.d;
+        const V4<TQ> v = *reinterpret_cast<const V4<TQ>*>(AB + k * ABW + ((g4 ^ sw(k)) << 2));
+        a0 += prow[k] * v.a; a1 += prow[k] * v.b; a2 += prow[k] * v.c; a3 += prow[k] * v.d;
       }
       V4<TQ> o; o.a = a0; o.b = a1; o.c = a2; o.d = a3;
       *reinterpret_cast<V4<TQ>*>(S + L.T1 + r4 * ABW + 4 * g4) = o;
     }
     TQ t = 0;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) t += AB[k * ABW + vcol] * bc(pv, k);
+    for (int k = 0; k < NX; ++k) t += vc[k] * bc(pv, k);
     if (va < 3) t = pv;
     __syncthreads();
     // ---- Ph2: F' lower block-triangle = AB'^T T1'
@@ -568,7 +676,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
       TQ a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
       for (int k = 0; k < NX; ++k) {
-        const TQ p = AB[k * ABW + fa];
+        const TQ p = AB[abo(k, fa)];
         const V4<TQ> v = *reinterpret_cast<const V4<TQ>*>(S + L.T1 + k * ABW + 4 * fg);
         a0 += p * v.a; a1 += p * v.b; a2 += p * v.c; a3 += p * v.d;
       }
@@ -587,10 +695,9 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
         for (int b2 = 0; b2 <= a; ++b2) Lm[a][b2] = S[L.F + (10 + a) * ABW + 10 + b2];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const int iv = i * NU + a;
-        am[a] = polish && S[L.act + iv] != TQ(0);
-        if (!polish) Lm[a][a] += (TQ)(m.h * m.W[NX + a]) + S[L.ll + iv] / S[L.sl + iv] + S[L.lu + iv] / S[L.su + iv];
-        else Lm[a][a] += (TQ)(m.h * m.W[NX + a]);
+        const TQ rt = S[L.rt + i * NU + a];
+        am[a] = rt < TQ(0);
+        Lm[a][a] += rt;
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a)
@@ -610,10 +717,10 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
         id[c] = trsqrt(d);
 #pragma unroll
         for (int a = c + 1; a < 4; ++a) {
-          TQ s = Lm[a][c];
+          TQ s2 = Lm[a][c];
 #pragma unroll
-          for (int k = 0; k < c; ++k) s -= Lm[a][k] * Lm[c][k];
-          Lm[a][c] = s * id[c];
+          for (int k = 0; k < c; ++k) s2 -= Lm[a][k] * Lm[c][k];
+          Lm[a][c] = s2 * id[c];
         }
       }
       if (!pd) ok = false;
@@ -624,21 +731,23 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
       // forward solve G y' = y, backward solve G^T x = y'
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        TQ s = y[c];
+        TQ s2 = y[c];
 #pragma unroll
-        for (int k = 0; k < c; ++k) s -= Lm[c][k] * y[k];
-        y[c] = s * id[c];
+        for (int k = 0; k < c; ++k) s2 -= Lm[c][k] * y[k];
+        y[c] = s2 * id[c];
       }
 #pragma unroll
       for (int c = 3; c >= 0; --c) {
-        TQ s = y[c];
+        TQ s2 = y[c];
 #pragma unroll
-        for (int k = c + 1; k < 4; ++k) s -= Lm[k][c] * y[k];
-        y[c] = s * id[c];
+        for (int k = c + 1; k < 4; ++k) s2 -= Lm[k][c] * y[k];
+        y[c] = s2 * id[c];
       }
       // vector part: gt_j on lanes 13..16, broadcast
       TQ gt = (va >= NX) ? S[L.rho + i * NU + vj] + t : TQ(0);
-      if (va >= NX && am[vj]) gt = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (va >= NX && vj == c && am[c]) gt = 0;
       const TQ g0 = bc(gt, 13), g1 = bc(gt, 14), g2 = bc(gt, 15), g3 = bc(gt, 16);
       if (lane < NX) {
         TQ* Kc = S + L.K + i * KS + lane;
@@ -650,7 +759,11 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
           TQ* Li = S + L.Linv + i * 16 + vj * 4;
 #pragma unroll
           for (int c = 0; c < 4; ++c) Li[c] = y[c];
-          S[L.kv + i * NU + vj] = am[vj] ? TQ(0) : -(y[0] * g0 + y[1] * g1 + y[2] * g2 + y[3] * g3);
+          TQ kvv = -(y[0] * g0 + y[1] * g1 + y[2] * g2 + y[3] * g3);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (vj == c && am[c]) kvv = 0;
+          S[L.kv + i * NU + vj] = kvv;
         }
         pv = 0;
       }
@@ -678,6 +791,8 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
       V4<TQ> ov; ov.a = o[0]; ov.b = o[1]; ov.c = o[2]; ov.d = o[3];
       *reinterpret_cast<V4<TQ>*>(S + L.P + (1 - pc) * ABS + r4 * ABW + 4 * g4) = ov;
     }
+#pragma unroll
+    for (int k = 0; k < NX; ++k) vc[k] = vn[k];
     __syncthreads();
   }
   __syncthreads();
@@ -689,7 +804,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
 // vector sweeps.  Continues from the current (z, sl, su, ll, lu, dx, grad) until |r_d| <= tol*gm and
 // mu <= tol.  returns 0 converged / 1 NaN / 2 iteration cap / 4 stage Hessian not positive definite
 template <typename TQ>
-__device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ tol, const TQ gm, int& it) {
+__device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
   int status = 2;
   const int maxit = m.qp_max_iter;
@@ -706,22 +821,25 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     // predictor: (H + Sigma) dza = -grad
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + i];
     __syncthreads();
-    if (!riccati_factor(m, S, L, false)) { status = 4; break; }
-    riccati_forward(m, S, L, L.dza);
+    PF_START();
+    const bool fok = riccati_factor(m, S, L, false);
+    PF_STOP(PF_FACTOR);
+    if (!fok) { status = 4; break; }
+    PF_START(); riccati_forward(m, S, L, L.dza); PF_STOP(PF_FWD);
     TQ aff = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dl = -ll - ll / sl * d, du = -lu + lu / su * d;
-      if (d < 0) aff = tmin(aff, -sl / d);
-      if (d > 0) aff = tmin(aff, su / d);
-      if (dl < 0) aff = tmin(aff, -ll / dl);
-      if (du < 0) aff = tmin(aff, -lu / du);
+      const TQ dl = -ll - tdiv(ll, sl) * d, du = -lu + tdiv(lu, su) * d;
+      if (d < 0) aff = tmin(aff, tdiv(-sl, d));
+      if (d > 0) aff = tmin(aff, tdiv(su, d));
+      if (dl < 0) aff = tmin(aff, tdiv(-ll, dl));
+      if (du < 0) aff = tmin(aff, tdiv(-lu, du));
     }
     aff = wave_min(aff);
     TQ mua = 0;
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dl = -ll - ll / sl * d, du = -lu + lu / su * d;
+      const TQ dl = -ll - tdiv(ll, sl) * d, du = -lu + tdiv(lu, su) * d;
       mua += (sl + aff * d) * (ll + aff * dl) + (su - aff * d) * (lu + aff * du);
     }
     mua = wave_sum(mua) / (2 * nv);
@@ -730,26 +848,26 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     // corrector rhs r = -rd + rcl/sl - rcu/su ; linear term rho = -r
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dl = -ll - ll / sl * d, du = -lu + lu / su * d;
+      const TQ dl = -ll - tdiv(ll, sl) * d, du = -lu + tdiv(lu, su) * d;
       const TQ rcl = -sl * ll + sigma * mu - d * dl;
       const TQ rcu = -su * lu + sigma * mu + d * du;
       const TQ rd = S[L.grad + i] - ll + lu;
-      S[L.rho + i] = rd - rcl / sl + rcu / su;
+      S[L.rho + i] = rd - tdiv(rcl, sl) + tdiv(rcu, su);
     }
     __syncthreads();
-    riccati_backward_vec(m, S, L, false);
-    riccati_forward(m, S, L, L.dz);
+    PF_START(); riccati_backward_vec(m, S, L, false); PF_STOP(PF_BWD);
+    PF_START(); riccati_forward(m, S, L, L.dz); PF_STOP(PF_FWD);
     TQ ap = 1, ad = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dla = -ll - ll / sl * da, dua = -lu + lu / su * da;
+      const TQ dla = -ll - tdiv(ll, sl) * da, dua = -lu + tdiv(lu, su) * da;
       const TQ rcl = -sl * ll + sigma * mu - da * dla;
       const TQ rcu = -su * lu + sigma * mu + da * dua;
-      const TQ dl = (rcl - ll * d) / sl, du = (rcu + lu * d) / su;
-      if (d < 0) ap = tmin(ap, -sl / d);
-      if (d > 0) ap = tmin(ap, su / d);
-      if (dl < 0) ad = tmin(ad, -ll / dl);
-      if (du < 0) ad = tmin(ad, -lu / du);
+      const TQ dl = tdiv(rcl - ll * d, sl), du = tdiv(rcu + lu * d, su);
+      if (d < 0) ap = tmin(ap, tdiv(-sl, d));
+      if (d > 0) ap = tmin(ap, tdiv(su, d));
+      if (dl < 0) ad = tmin(ad, tdiv(-ll, dl));
+      if (du < 0) ad = tmin(ad, tdiv(-lu, du));
     }
     ap = wave_min(ap);
     ad = wave_min(ad);
@@ -758,16 +876,16 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     ad = tmin(TQ(1), tau * ad);
     for (int i = tid; i < nv; i += 64) {
       const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dla = -ll - ll / sl * da, dua = -lu + lu / su * da;
+      const TQ dla = -ll - tdiv(ll, sl) * da, dua = -lu + tdiv(lu, su) * da;
       const TQ rcl = -sl * ll + sigma * mu - da * dla;
       const TQ rcu = -su * lu + sigma * mu + da * dua;
-      const TQ dl = (rcl - ll * d) / sl, du = (rcu + lu * d) / su;
+      const TQ dl = tdiv(rcl - ll * d, sl), du = tdiv(rcu + lu * d, su);
       S[L.z + i] += ap * d; S[L.sl + i] = sl + ap * d; S[L.su + i] = su - ap * d;
       S[L.ll + i] = ll + ad * dl; S[L.lu + i] = lu + ad * du;
     }
     for (int i = tid; i < (N + 1) * NX; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
     __syncthreads();
-    adjoint(m, S, L);
+    PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
   }
   return status;
 }
@@ -778,7 +896,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename TQ>
-__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ gm, int& passes) {
+__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ gm, int& passes PF_ARG) {
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
   for (int i = tid; i < nv; i += 64)
     S[L.act + i] = S[L.ll + i] > S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > S[L.su + i] ? TQ(1) : TQ(0));
@@ -794,8 +912,8 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       else if (a > 0) S[L.z + i] = S[L.ub + i];
     }
     __syncthreads();
-    rollout(m, S, L, L.dx, L.z, true);
-    adjoint(m, S, L);
+    PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
     // stationarity on the free set, worst multiplier sign violation on the pinned set
     TQ gF = 0, vmax = 0;
     for (int i = tid; i < nv; i += 64) {
@@ -825,10 +943,11 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     }
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + i];
     __syncthreads();
-    if (refactor) { if (!riccati_factor(m, S, L, true)) return false; }
-    else riccati_backward_vec(m, S, L, true);
+    PF_START();
+    if (refactor) { const bool fok = riccati_factor(m, S, L, true); PF_STOP(PF_FACTOR); if (!fok) return false; }
+    else { riccati_backward_vec(m, S, L, true); PF_STOP(PF_BWD); }
     refactor = false;
-    riccati_forward(m, S, L, L.dz);
+    PF_START(); riccati_forward(m, S, L, L.dz); PF_STOP(PF_FWD);
     TQ alpha = 1;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
@@ -859,7 +978,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
 // settle (degenerate cycling), fall back to IPM iterations down to the final tolerance.
 // On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory; returns passes.
 template <typename TQ>
-__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* status) {
+__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* status PF_ARG) {
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
   // interior start
   for (int i = tid; i < nv; i += 64) {
@@ -868,27 +987,27 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
     S[L.z + i] = z0; S[L.sl + i] = z0 - lb; S[L.su + i] = ub - z0;
   }
   __syncthreads();
-  rollout(m, S, L, L.dx, L.z, true);
-  adjoint(m, S, L);
+  PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+  PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
   TQ gm = 1;
   for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + i]));
   gm = wave_max(gm);
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = TQ(0.1) * gm / S[L.sl + i]; S[L.lu + i] = TQ(0.1) * gm / S[L.su + i]; }
   __syncthreads();
   int it = 0, passes = 0;
-  int st = ipm_run(m, S, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it);
+  int st = ipm_run(m, S, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
-    if (!polish(m, S, L, gm, passes)) {
+    if (!polish(m, S, L, gm, passes PF_PASS)) {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
-      rollout(m, S, L, L.dx, L.z, true);
-      adjoint(m, S, L);
-      st = ipm_run(m, S, L, m.qp_tol, gm, it);
+      PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+      PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+      st = ipm_run(m, S, L, m.qp_tol, gm, it PF_PASS);
     }
   }
-  rollout(m, S, L, L.dx, L.z, true);   // state trajectory of the returned z
+  PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);   // state trajectory of the returned z
   *status = st;
   return it + passes;
 }
@@ -962,6 +1081,12 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   double* D = reinterpret_cast<double*>(smem_raw);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
   const bool gp = nb > 0;
+#ifdef MPCQ_PROFILE
+  Prof pf;
+  for (int k = 0; k < PF_N; ++k) pf.acc[k] = 0;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  pf.t = t_begin;
+#endif
   // ---- load persistent state (lane-contiguous records)
   double* gX = st.X + (size_t)b * (N + 1) * NX;
   double* gU = st.U + (size_t)b * N * NU;
@@ -1016,16 +1141,19 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
     }
   }
   __syncthreads();
+  PF_STOP(PF_LOAD);
   // ---- 1. shooting
   shoot_states(m, D, S, L, gp);
   __syncthreads();
+  PF_STOP(PF_SHOOT_X);
   shoot_sens(m, S, L);
-  __syncthreads();   // shooting records (union region) are dead from here on
+  __syncthreads();
+  PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
   if (tid < NX) S[L.dx + tid] = (TQ)(D[L.x0 + tid] - D[L.X + tid]);   // dx_0 = x_meas - X_0 (lbx = ubx = x_init)
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  const int iters = solve_qp(m, S, L, &status);
+  const int iters = solve_qp(m, S, L, &status PF_PASS);
   // ---- 3. full step (iterate accumulated in double)
   for (int i = tid; i < (N + 1) * NX; i += 64) { const double v = D[L.X + i] + (double)S[L.dx + i]; D[L.X + i] = v; gX[i] = v; }
   for (int i = tid; i < nv; i += 64) { const double v = D[L.U + i] + (double)S[L.z + i]; D[L.U + i] = v; gU[i] = v; }
@@ -1049,6 +1177,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   if (bad) status = 1;
   if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; }
   if (tid < NU) st.w[(size_t)b * NU + tid] = D[L.U + tid];
+  PF_START();
   if (!(mode & MODE_POST)) return;
   // ---- 4. post: nominal prediction, cursor, drag estimate, RGP regress, statistics
   double* vbad = D + L.x0 + NX;   // [v_body(3), a_drag(3)]
@@ -1090,6 +1219,12 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   }
   __syncthreads();
   if (gp) rgp_regress(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3);
+#ifdef MPCQ_PROFILE
+  PF_STOP(PF_POST);
+  pf.acc[PF_TOTAL] = __builtin_readcyclecounter() - t_begin;
+  if (tid == 0 && st.prof)
+    for (int k = 0; k < PF_N; ++k) st.prof[(size_t)b * PF_N + k] = pf.acc[k];
+#endif
 }
 
 // ------------------------------------------------------------------ small explicit-path kernels

@@ -59,6 +59,38 @@ template <typename T> inline T __shfl_xor(T v, int mask) {
 }
 inline float __expf(float x) { return std::exp(x); }
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+inline int __double2loint(double d) { uint64_t u; std::memcpy(&u, &d, 8); return (int)(uint32_t)u; }
+inline int __double2hiint(double d) { uint64_t u; std::memcpy(&u, &d, 8); return (int)(uint32_t)(u >> 32); }
+inline double __hiloint2double(int hi, int lo) { uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; std::memcpy(&d, &u, 8); return d; }
+inline unsigned long long __builtin_readcyclecounter_emu() { return 0; }
+// v_readlane_b32: every lane receives lane `src`'s value (src wave-uniform)
+inline int __builtin_amdgcn_readlane(int v, int src) {
+  uint64_t* ex = emu::exchange();
+  const unsigned t = emu::cur->tid.x;
+  ex[t] = (uint32_t)v;
+  emu::sync();
+  const int r = (int)(uint32_t)ex[(t & ~63u) | ((unsigned)src & 63u)];
+  emu::sync();
+  return r;
+}
+// DPP: quad_perm (ctrl 0x00..0xFF) and row_ror:n (0x121..0x12F) with all rows/banks enabled
+inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool) {
+  (void)old;
+  uint64_t* ex = emu::exchange();
+  const unsigned t = emu::cur->tid.x;
+  ex[t] = (uint32_t)v;
+  emu::sync();
+  unsigned src;
+  if (ctrl <= 0xFF) src = (t & ~3u) | ((unsigned)(ctrl >> (2 * (t & 3))) & 3u);
+  else if (ctrl >= 0x121 && ctrl <= 0x12F) src = (t & ~15u) | ((t - (unsigned)(ctrl - 0x120)) & 15u);
+  else { std::abort(); }
+  const int r = (int)(uint32_t)ex[src];
+  emu::sync();
+  return r;
+}
 template <typename T> inline T __shfl(T v, int src) {
   static_assert(sizeof(T) <= 8, "shuffle payload");
   uint64_t* ex = emu::exchange();

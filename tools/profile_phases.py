@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader-cycle breakdown of the fused step kernel (needs libmpcq_prof.so,
+`make -C mpc_quad_ros_amd/csrc prof`).  Never used for reported timings: stamps perturb the kernel."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mpc_quad_ros_amd.engine import Engine  # noqa: E402
+from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace  # noqa: E402
+from mpc_quad_ros_amd.trajectories import swarm_trajectories  # noqa: E402
+
+NAMES = ["load", "shoot_x", "shoot_s", "factor", "fwd", "bwd", "adjoint", "rollout", "elem", "post", "total"]
+
+
+def main():
+    prec = 1 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else 0
+    B, N, nb = 1024, 20, 10
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    lib = os.path.join(ROOT, "mpc_quad_ros_amd", "libmpcq_prof.so")
+    e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=prec), lib_path=lib)
+    traj, lens = swarm_trajectories(2026, 0, B)
+    e.set_trajectories(traj, lens)
+    e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
+    e.lib.mpcq_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    acc = np.zeros((B, 16))
+    mx = np.zeros(16)
+    its = []
+    for k in range(steps):
+        e.sim_steps(1, 2, 5e-3)
+        out = np.zeros((B, 16), dtype=np.uint64)
+        rc = e.lib.mpcq_debug_profile(e.h, out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        acc += out
+        worst = out[:, 10].argmax()
+        mx += out[worst]
+        its.append(e.get_qp_iter())
+    its = np.array(its)
+    mean = acc.mean(axis=0) / steps
+    mxs = mx / steps
+    print(f"precision {'f32' if prec else 'f64'}  B={B} N={N} nb={nb}  steps={steps}  passes mean {its.mean():.2f} max {its.max()}")
+    print(f"{'phase':10s} {'mean cycles':>12s} {'share':>7s} {'slowest-quad cycles':>20s}")
+    for i, n in enumerate(NAMES):
+        print(f"{n:10s} {mean[i]:12.0f} {100 * mean[i] / mean[10]:6.1f}% {mxs[i]:20.0f}")
+    other = mean[10] - mean[:10].sum()
+    print(f"{'other':10s} {other:12.0f} {100 * other / mean[10]:6.1f}%")
+
+
+if __name__ == "__main__":
+    main()
