@@ -27,7 +27,8 @@
 namespace mpcq {
 
 constexpr int NX = 13, NU = 4, NY = 17;
-constexpr int ABW = 16;          // row stride of AB' = columns 3..16 of [A|B] (cols 0..2 of A are [I;0])
+constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
+constexpr int VS = 16;           // stride of state-sized QP vectors (internal order, 13 used)
 constexpr int ABS = NX * ABW;    // per-stage stride of AB'
 constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded to 16)
 constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
@@ -92,11 +93,12 @@ struct DevState {
 
 // ------------------------------------------------------------------ LDS layout
 // doubles first (offsets in doubles from the LDS base), then the TQ region (offsets in TQ elements
-// from the TQ base = base + dbytes).
+// from the TQ base = base + dbytes).  State-sized QP vectors use the INTERNAL state order
+// [q(4) v(3) r(3) p(3)] (position last) and a stride of 16.
 struct Lds {
   int X, U, x0, dbytes;
-  int AB, c, qv, r0, lb, ub, alpha, basis;
-  int z, sl, su, ll, lu, grad, dza, dz, rho, kv, act, rt, dx, Dx, K, Linv, P, T1, F;
+  int AB, c, qv, r0, lb, ub, alpha, basis, wq;
+  int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv, spv;
   int sub, rgp, qtotal;
 };
 __host__ __device__ inline int al4(int v) { return (v + 3) & ~3; }
@@ -110,24 +112,28 @@ __host__ __device__ inline Lds lds_layout(int N, int nb) {
   L.dbytes = o * 8;
   o = 0;
   const int nv = N * NU;
-  L.AB = take(N * ABS);
-  L.c = take(N * NX);
-  L.qv = take((N + 1) * NX);
+  L.AB = take(N * ABS + VS);   // + one zero block read by padding lanes
+  L.c = take(N * VS);
+  L.qv = take((N + 1) * VS);
   L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv);
   L.alpha = take(3 * nb);
   L.basis = take(3 * nb);
+  L.wq = take(3 * VS);   // stage / terminal state weights in internal order, input weights
   const int u0 = o;  // ---- union: shooting records | QP workspace | RGP workspace
   L.sub = u0;
   const int sub_end = u0 + al4(N * SUBS);
   L.z = take(nv); L.sl = take(nv); L.su = take(nv); L.ll = take(nv); L.lu = take(nv);
-  L.grad = take(nv); L.dza = take(nv); L.dz = take(nv); L.rho = take(nv); L.kv = take(nv); L.act = take(nv); L.rt = take(nv);
-  L.dx = take((N + 1) * NX);
-  L.Dx = take((N + 1) * NX);
+  L.dza = take(nv); L.dz = take(nv); L.rho = take(nv); L.act = take(nv); L.rt = take(nv);
+  L.grad = take(N * VS);   // slots 10..13 of each stage: d objective / d z
+  L.vin = take(N * VS);    // per-sweep input vector: slots 0..3 feed-forward k_i, slots 10..13 sweep-specific
+  L.dx = take((N + 1) * VS);
+  L.Dx = take((N + 1) * VS);
   L.K = take(N * KS);
   L.Linv = take(N * 16);
-  L.P = take(2 * ABS);
-  L.T1 = take(ABS);
-  L.F = take(14 * ABW);
+  L.sF = take(4 * VS);
+  L.sT = take(3 * VS);
+  L.stv = take(2 * VS);
+  L.spv = take(VS);
   const int qp_end = o;
   L.rgp = u0;
   const int rgp_end = u0 + al4(3 * nb * nb) + 5 * al4(3 * nb) + 32;
@@ -170,20 +176,81 @@ template <typename T> __device__ inline T wave_max(T v) { return wave_reduce(v, 
 template <typename T> __device__ inline T wave_min(T v) { return wave_reduce(v, [](T a, T b) { return a < b ? a : b; }); }
 __device__ inline float  tdiv(float a, float b)  { return __fdividef(a, b); }   // a * rcp(b): ~1 ulp, QP arithmetic only
 __device__ inline double tdiv(double a, double b) { return a / b; }
+
+// internal state order of the QP: [q v r p]; o2i(original index) / i2o(internal index)
+__host__ __device__ inline int o2i(int o) { return o < 3 ? o + 10 : o - 3; }
+__host__ __device__ inline int i2o(int k) { return k < 10 ? k + 3 : k - 10; }
+
+// ---- matrix-core tiles.  One v_mfma_*_16x16x4 per call: D = A(16x4) B(4x16) + C with lane (h = lane>>4,
+// c = lane&15) holding A[c][h], B[h][c] and four C/D elements D[RI(reg,h)][c].  A K=16 product is four
+// calls; since the k index is only summed over, step s of lane group h may carry ANY k as long as A and
+// B agree: we use k = RI(s,h), the same map as the C/D rows, so an accumulator tile can be fed straight
+// back as the B operand of the next product (and a symmetric one as the A operand) without leaving
+// registers.  RI differs between the f32 and f64 instructions.
+template <typename TQ> __device__ inline int RI(int s, int h) { return sizeof(TQ) == 4 ? 4 * h + s : h + 4 * s; }
+__device__ inline void mfma(float (&acc)[4], float a, float b) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 cc = {acc[0], acc[1], acc[2], acc[3]};
+  cc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, cc, 0, 0, 0);
+  acc[0] = cc[0]; acc[1] = cc[1]; acc[2] = cc[2]; acc[3] = cc[3];
+}
+__device__ inline void mfma(double (&acc)[4], double a, double b) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 cc = {acc[0], acc[1], acc[2], acc[3]};
+  cc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cc, 0, 0, 0);
+  acc[0] = cc[0]; acc[1] = cc[1]; acc[2] = cc[2]; acc[3] = cc[3];
+}
+// A state-sized vector rides in column 14 of a tile: lane (h, 14) holds slots RI(s,h), s = 0..3.
+__device__ inline void vl_load(const float* base, int h, float (&v)[4]) {   // slots 4h..4h+3: one 128-bit read
+  const V4<float> t = *reinterpret_cast<const V4<float>*>(base + 4 * h);
+  v[0] = t.a; v[1] = t.b; v[2] = t.c; v[3] = t.d;
+}
+__device__ inline void vl_store(float* base, int h, const float (&v)[4]) {
+  V4<float> t; t.a = v[0]; t.b = v[1]; t.c = v[2]; t.d = v[3];
+  *reinterpret_cast<V4<float>*>(base + 4 * h) = t;
+}
+__device__ inline void vl_load(const double* base, int h, double (&v)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) v[s] = base[h + 4 * s];
+}
+__device__ inline void vl_store(double* base, int h, const double (&v)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) base[h + 4 * s] = v[s];
+}
+// Operand addressing that is valid on every lane (padding lanes read the zero block behind AB'' with
+// stride 0), so operand loads are unconditional and can be issued a stage ahead.
+// k-major operand: lane (h,c) <- AB''[RI(s,h)][c]
+template <typename TQ> struct KMaj {
+  int off[4], str[4];
+  __device__ inline KMaj(const Lds& L, int N, int h, int c) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = RI<TQ>(s, h);
+      off[s] = k < NX ? L.AB + k * ABW + c : L.AB + N * ABS + c;
+      str[s] = k < NX ? ABS : 0;
+    }
+  }
+  __device__ inline void load(const TQ* S, int i, TQ (&o)[4]) const {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o[s] = S[off[s] + i * str[s]];
+  }
+};
+// row-major operand: lane (h,c) <- M[c][RI(s,h)] for a row-major matrix of `rows` rows at `base` (stage stride `sst`)
+template <typename TQ> struct RMaj {
+  int off, str, hh;
+  __device__ inline RMaj(const Lds& L, int N, int base, int sst, int rows, int h, int c) {
+    off = c < rows ? base + c * ABW : L.AB + N * ABS;
+    str = c < rows ? sst : 0;
+    hh = h;
+  }
+  __device__ inline void load(const TQ* S, int i, TQ (&o)[4]) const { vl_load(S + off + i * str, hh, o); }
+};
 __device__ inline float  texp(float x)  { return __expf(x); }
 __device__ inline double texp(double x) { return exp(x); }
 __device__ inline float  trsqrt(float x)  { return rsqrtf(x); }
 __device__ inline double trsqrt(double x) { return 1.0 / sqrt(x); }
 __device__ inline float  tabs(float x)  { return fabsf(x); }
 __device__ inline double tabs(double x) { return fabs(x); }
-
-// AB' is stored with an XOR swizzle of its 4-float column groups, element (r, c) at
-//   r*ABW + (((c >> 2) ^ sw(r)) << 2) + (c & 3),  sw(r) = (r >> 1) & 3,
-// so that both access directions are (nearly) bank-conflict free: a fixed row read across 14 column
-// lanes stays a permutation of one 16-float row, and a fixed column read across 13 row lanes spreads
-// over 8 banks instead of 2.
-__device__ inline int sw(int r) { return (r >> 1) & 3; }
-__device__ inline int abo(int r, int c) { return r * ABW + ((((c >> 2) ^ sw(r)) << 2) | (c & 3)); }
 
 template <typename T> __device__ inline void rotmat(const T* q, T* R) {
   const T qw = q[0], qx = q[1], qy = q[2], qz = q[3];
@@ -380,7 +447,7 @@ __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* 
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const double gap = (D[L.X + i * NX + j] - D[L.X + (i + 1) * NX + j]) + (double)(h / 6 * (acc[j] + k[j]));
-      S[L.c + i * NX + j] = (TQ)gap;
+      S[L.c + i * VS + o2i(j)] = (TQ)gap;
     }
   }
 }
@@ -435,50 +502,66 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, const Lds& L) {
     }
     TQ* AB = S + L.AB + i * ABS;
 #pragma unroll
-    for (int r = 0; r < NX; ++r) AB[abo(r, jp)] = ((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r];
+    for (int r = 0; r < NX; ++r) AB[o2i(r) * ABW + jp] = ((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r];
   }
   // zero the two pad columns (read by the vectorised 4-wide loads)
-  for (int it = threadIdx.x; it < N * NX * 2; it += 64) {
-    const int row = it >> 1, i = row / NX, r = row - i * NX;
-    S[L.AB + i * ABS + abo(r, 14 + (it & 1))] = 0;
-  }
+  for (int it = threadIdx.x; it < N * NX * 2; it += 64) S[L.AB + (it >> 1) * ABW + 14 + (it & 1)] = 0;
+  for (int it = threadIdx.x; it < N * 3; it += 64) S[L.c + (it / 3) * VS + NX + it % 3] = 0;
 }
 
 // ------------------------------------------------------------------ QP: vector sweeps
 // QP in (dx, du): min sum_i 1/2 dx'Q_i dx + qv_i'dx + 1/2 du'R du + r0_i'du  s.t. dx_{i+1} = A dx_i + B du_i + c_i,
 // dx_0 = x0 - X_0, lb <= du <= ub.  Q_i = h W_x (i<N) / W_e, R = h W_u diagonal; qv, r0, lb, ub, c prepared by
-// the caller.  Vectors of length 13 live on lanes 0..12, input-sized quantities on lanes 13..16.
+// the caller (internal state order).  With position last, [A|B] = [AB''(:,0:10) | [0;I] | AB''(:,10:14)]: the 14
+// columns of AB'' (10 states q,v,r + 4 inputs) fit one 16-wide matrix-core tile and the position columns
+// are handled as identity.  All sweeps are matrix-core products with the vector riding in column 14.
 
-// column `col` of a stage's AB' (13 values, one per row k), into registers
-template <typename TQ> __device__ inline void load_col(const TQ* ab, int col, TQ (&o)[NX]) {
+// per-lane slot classes of the four registers of a column-14 vector, as 0/1 multipliers
+template <typename TQ> struct Sel {
+  TQ A[4], P[4], U[4], K[4];   // slot < 10 (q,v,r) | position 10..12 | input slots 10..13 | slots 0..3
+  __device__ inline Sel(int h) {
 #pragma unroll
-  for (int k = 0; k < NX; ++k) o[k] = ab[abo(k, col)];
-}
-// row r of a stage's AB' (14 values + 2 pads) into registers, logical column order
-template <typename TQ> __device__ inline void load_row(const TQ* ab, int r, TQ (&o)[16]) {
-  const int s = sw(r);
-#pragma unroll
-  for (int c = 0; c < 16; ++c) o[c] = ab[r * ABW + ((((c >> 2) ^ s) << 2) | (c & 3))];
-}
+    for (int s = 0; s < 4; ++s) {
+      const int slot = RI<TQ>(s, h);
+      A[s] = slot < 10 ? TQ(1) : TQ(0);
+      P[s] = (slot >= 10 && slot < NX) ? TQ(1) : TQ(0);
+      U[s] = (slot >= 10 && slot < 14) ? TQ(1) : TQ(0);
+      K[s] = slot < NU ? TQ(1) : TQ(0);
+    }
+  }
+};
+// compile-time position of QP-input j inside a column-14 vector: slot 10 + j = RI(s, h)
+template <typename TQ> __device__ constexpr int in_h(int j) { return sizeof(TQ) == 4 ? (10 + j) / 4 : (10 + j) % 4; }
+template <typename TQ> __device__ constexpr int in_s(int j) { return sizeof(TQ) == 4 ? (10 + j) % 4 : (10 + j) / 4; }
+__host__ __device__ inline int GI(int i) { return (i >> 2) * VS + 10 + (i & 3); }   // input i of the nv-vector inside a 16-stride array
 
-// forward rollout dx_{i+1} = A dx_i + B z_i (+ c_i); dx_0 taken from S[dxo + 0..12]
+// forward rollout dx_{i+1} = A dx_i + B z_i (+ c_i); dx_0 taken from S[dxo + 0..15]
 template <typename TQ>
 __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, const Lds& L, int dxo, int zo, bool with_c) {
-  const int N = m.N, lane = threadIdx.x, r = lane < NX ? lane : 0;
-  TQ xr = S[dxo + r];
-  TQ cur[16], nxt[16];
-  load_row(S + L.AB, r, cur);
+  const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  const bool vl = c == 14;
+  for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[zo + i];
+  __syncthreads();
+  const Sel<TQ> sel(h);
+  const RMaj<TQ> rm(L, N, L.AB, ABS, NX, h, c);
+  TQ vA[4], cur[4], nxt[4];
+  vl_load(S + dxo, h, vA);
+  rm.load(S, 0, cur);
   for (int i = 0; i < N; ++i) {
-    if (i + 1 < N) load_row(S + L.AB + (i + 1) * ABS, r, nxt);
-    TQ t = (with_c ? S[L.c + i * NX + r] : TQ(0)) + (r < 3 ? xr : TQ(0));
+    rm.load(S, i + 1 < N ? i + 1 : i, nxt);
+    TQ zv[4], cv[4], vB[4], acc[4];
+    vl_load(S + L.vin + i * VS, h, zv);
+    vl_load(S + L.c + i * VS, h, cv);
 #pragma unroll
-    for (int j = 0; j < NU; ++j) t += cur[10 + j] * S[zo + i * NU + j];
+    for (int s = 0; s < 4; ++s) {
+      vB[s] = sel.A[s] * vA[s] + sel.U[s] * zv[s];
+      acc[s] = (with_c ? cv[s] : TQ(0)) + sel.P[s] * vA[s];
+    }
 #pragma unroll
-    for (int k = 3; k < NX; ++k) t += cur[k - 3] * bc(xr, k);
-    xr = t;
-    if (lane < NX) S[dxo + (i + 1) * NX + lane] = t;
+    for (int s = 0; s < 4; ++s) mfma(acc, cur[s], vB[s]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; cur[s] = nxt[s]; }
+    if (vl) vl_store(S + dxo + (i + 1) * VS, h, vA);
   }
   __syncthreads();
 }
@@ -486,57 +569,75 @@ __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, const Lds& L, int d
 // adjoint sweep: grad = d/dz of the QP objective at (dx(z), z)
 template <typename TQ>
 __device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, const Lds& L) {
-  const int N = m.N, lane = threadIdx.x;
-  const int a = lane < NY ? lane : 0, col = a >= 3 ? a - 3 : 0, ax = a < NX ? a : 0, au = a >= NX ? a - NX : 0;
-  const TQ qd = a < NX ? (TQ)(m.h * m.W[a]) : TQ(0), qe = a < NX ? (TQ)m.We[a] : TQ(0);
-  const TQ rd = (a >= NX) ? (TQ)(m.h * m.W[a]) : TQ(0);
-  TQ pi = a < NX ? qe * S[L.dx + N * NX + a] + S[L.qv + N * NX + a] : TQ(0);
-  TQ cur[NX], nxt[NX];
-  load_col(S + L.AB + (N - 1) * ABS, col, cur);
+  const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  const bool vl = c == 14;
+  for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
+  __syncthreads();
+  const Sel<TQ> sel(h);
+  const KMaj<TQ> km(L, N, h, c);
+  TQ qd[4], qe[4], pi[4], dxv[4], qvv[4], cur[4], nxt[4];
+  vl_load(S + L.wq, h, qd);
+  vl_load(S + L.wq + VS, h, qe);
+  vl_load(S + L.dx + N * VS, h, dxv);
+  vl_load(S + L.qv + N * VS, h, qvv);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) pi[s] = qe[s] * dxv[s] + qvv[s];
+  km.load(S, N - 1, cur);
   for (int i = N - 1; i >= 0; --i) {
-    if (i > 0) load_col(S + L.AB + (i - 1) * ABS, col, nxt);
-    const TQ add = a < NX ? qd * S[L.dx + i * NX + ax] + S[L.qv + i * NX + ax]
-                          : rd * S[L.z + i * NU + au] + S[L.r0 + i * NU + au];
-    TQ t = 0;
+    km.load(S, i > 0 ? i - 1 : 0, nxt);
+    TQ gv[4], acc[4] = {0, 0, 0, 0};
+    vl_load(S + L.dx + i * VS, h, dxv);
+    vl_load(S + L.qv + i * VS, h, qvv);
+    vl_load(S + L.vin + i * VS, h, gv);
 #pragma unroll
-    for (int k = 0; k < NX; ++k) t += cur[k] * bc(pi, k);
-    if (a < 3) t = pi;
-    t += add;
-    if (lane < NX) pi = t;
-    else if (lane < NY) S[L.grad + i * NU + au] = t;
+    for (int s = 0; s < 4; ++s) mfma(acc, cur[s], pi[s]);
+    TQ g[4];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) cur[k] = nxt[k];
+    for (int s = 0; s < 4; ++s) {
+      g[s] = acc[s] + gv[s];
+      pi[s] = sel.A[s] * acc[s] + sel.P[s] * pi[s] + (qd[s] * dxv[s] + qvv[s]);
+      cur[s] = nxt[s];
+    }
+    if (vl) vl_store(S + L.grad + i * VS, h, g);
   }
   __syncthreads();
 }
 
-// backward vector recursion with stored K, Linv: feed-forward kv for linear term rho
+// backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
 template <typename TQ>
 __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, const Lds& L, bool polish) {
-  const int N = m.N, lane = threadIdx.x;
-  const int a = lane < NY ? lane : 0, col = a >= 3 ? a - 3 : 0, j = a >= NX ? a - NX : 0, b = a < NX ? a : 0;
-  TQ pv = 0;
-  TQ cur[NX], nxt[NX];
-  load_col(S + L.AB + (N - 1) * ABS, col, cur);
+  const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
+  __syncthreads();
+  const Sel<TQ> sel(h);
+  const KMaj<TQ> km(L, N, h, c);
+  const int lj = lane < NU ? lane : 0;
+  TQ pv[4] = {0, 0, 0, 0}, cur[4], nxt[4];
+  km.load(S, N - 1, cur);
   for (int i = N - 1; i >= 0; --i) {
-    if (i > 0) load_col(S + L.AB + (i - 1) * ABS, col, nxt);
-    // per-lane coefficients of the second half: K[:,b] for lanes < 13, Linv[j][:] for lanes 13..16
-    const TQ* cf = lane < NX ? S + L.K + i * KS + b : S + L.Linv + i * 16 + j * 4;
-    const int cs = lane < NX ? ABW : 1;
-    const TQ c0 = cf[0], c1 = cf[cs], c2 = cf[2 * cs], c3 = cf[3 * cs];
-    const TQ rho = S[L.rho + i * NU + j];
-    TQ t = 0;
+    km.load(S, i > 0 ? i - 1 : 0, nxt);
+    TQ rv[4], acc[4] = {0, 0, 0, 0};
+    vl_load(S + L.vin + i * VS, h, rv);
+    const TQ kk = S[L.K + i * KS + h * ABW + c];
+    const V4<TQ> li = *reinterpret_cast<const V4<TQ>*>(S + L.Linv + i * 16 + lj * 4);
+    const TQ rtj = S[L.rt + i * NU + lj];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) t += cur[k] * bc(pv, k);
-    if (a < 3) t = pv;
-    TQ gt = (a >= NX) ? rho + t : TQ(0);
-    if (polish && a >= NX && S[L.act + i * NU + j] != TQ(0)) gt = 0;
-    const TQ g0 = bc(gt, 13), g1 = bc(gt, 14), g2 = bc(gt, 15), g3 = bc(gt, 16);
-    const TQ comb = c0 * g0 + c1 * g1 + c2 * g2 + c3 * g3;
-    pv = lane < NX ? t + comb : TQ(0);
-    if (a >= NX && lane < NY) S[L.kv + i * NU + j] = -comb;
+    for (int s = 0; s < 4; ++s) mfma(acc, cur[s], pv[s]);
+    // gt_j = rho_j + (B^T p)_j sits in slot 10+j of column 14; fetch the four of them as scalars
+    TQ g[4];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) cur[k] = nxt[k];
+    for (int j = 0; j < 4; ++j) g[j] = bc(acc[in_s<TQ>(j)] + rv[in_s<TQ>(j)], 16 * in_h<TQ>(j) + 14);
+    // p_i = A^T p_{i+1} + K^T gt  (one k=4 tile: A operand K[h][c], B operand gt_h in column 14; pinned rows of K are 0)
+    const TQ gh = h == 0 ? g[0] : (h == 1 ? g[1] : (h == 2 ? g[2] : g[3]));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s] = sel.A[s] * acc[s] + sel.P[s] * pv[s];
+    mfma(acc, kk, gh);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { pv[s] = acc[s]; cur[s] = nxt[s]; }
+    if (lane < NU) {
+      const TQ kvj = -(li.a * g[0] + li.b * g[1] + li.c * g[2] + li.d * g[3]);
+      S[L.vin + i * VS + lane] = (polish && rtj < TQ(0)) ? TQ(0) : kvj;
+    }
   }
   __syncthreads();
 }
@@ -544,155 +645,135 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, const 
 // forward sweep: Dx_0 = 0; dz_i = K_i Dx_i + k_i ; Dx_{i+1} = A Dx_i + B dz_i   (out: S[dzo], S[L.Dx])
 template <typename TQ>
 __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& L, int dzo) {
-  const int N = m.N, lane = threadIdx.x;
-  const int r = lane < NX ? lane : 0, j = (lane >= NX && lane < NY) ? lane - NX : 0;
-  TQ xr = 0;
-  if (lane < NX) S[L.Dx + lane] = 0;
-  // per-lane coefficient row over x_0..x_12: lanes < 13 -> row r of A (identity columns 0..2, then AB' cols 0..9),
-  // lanes 13..16 -> row j of K
-  TQ cur[NX], nxt[NX], bcur[NU], bnxt[NU];
-  auto load = [&](int i, TQ (&cx)[NX], TQ (&cb)[NU]) {
-    if (lane < NX) {
-      TQ row[16];
-      load_row(S + L.AB + i * ABS, r, row);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) cx[k] = lane == k ? TQ(1) : TQ(0);
-#pragma unroll
-      for (int k = 3; k < NX; ++k) cx[k] = row[k - 3];
-#pragma unroll
-      for (int k = 0; k < NU; ++k) cb[k] = row[10 + k];
-    } else {
-      const TQ* kr = S + L.K + i * KS + j * ABW;
-#pragma unroll
-      for (int k = 0; k < NX; ++k) cx[k] = kr[k];
-#pragma unroll
-      for (int k = 0; k < NU; ++k) cb[k] = 0;
-    }
-  };
-  load(0, cur, bcur);
+  const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15;
+  const bool vl = c == 14;
+  const Sel<TQ> sel(h);
+  const RMaj<TQ> rm(L, N, L.AB, ABS, NX, h, c), rk(L, N, L.K, KS, NU, h, c);
+  TQ vA[4] = {0, 0, 0, 0}, ac[4], an[4], kc[4], kn[4];
+  if (lane < VS) S[L.Dx + lane] = 0;
+  rm.load(S, 0, ac);
+  rk.load(S, 0, kc);
   for (int i = 0; i < N; ++i) {
-    if (i + 1 < N) load(i + 1, nxt, bnxt);
-    TQ t = lane < NX ? TQ(0) : S[L.kv + i * NU + j];
+    rm.load(S, i + 1 < N ? i + 1 : i, an);
+    rk.load(S, i + 1 < N ? i + 1 : i, kn);
+    TQ kv[4], acc[4];
+    vl_load(S + L.vin + i * VS, h, kv);
 #pragma unroll
-    for (int k = 0; k < NX; ++k) t += cur[k] * bc(xr, k);
-    const TQ d0 = bc(t, 13), d1 = bc(t, 14), d2 = bc(t, 15), d3 = bc(t, 16);
-    if (lane >= NX && lane < NY) S[dzo + i * NU + j] = t;
-    xr = lane < NX ? t + bcur[0] * d0 + bcur[1] * d1 + bcur[2] * d2 + bcur[3] * d3 : TQ(0);
-    if (lane < NX) S[L.Dx + (i + 1) * NX + lane] = xr;
+    for (int s = 0; s < 4; ++s) acc[s] = sel.K[s] * kv[s];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) cur[k] = nxt[k];
+    for (int s = 0; s < 4; ++s) mfma(acc, kc[s], vA[s]);     // dz = K Dx + k : slots 0..3 of column 14
+    TQ d[4];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) bcur[k] = bnxt[k];
+    for (int j = 0; j < 4; ++j) d[j] = sizeof(TQ) == 4 ? bc(acc[j], 14) : bc(acc[0], 16 * j + 14);   // slot j = RI(s,h)
+    if (lane < NU) S[dzo + i * NU + lane] = lane == 0 ? d[0] : (lane == 1 ? d[1] : (lane == 2 ? d[2] : d[3]));
+    TQ vB[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { vB[s] = sel.A[s] * vA[s]; acc[s] = sel.P[s] * vA[s]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (h == in_h<TQ>(j)) vB[in_s<TQ>(j)] = d[j];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma(acc, ac[s], vB[s]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; ac[s] = an[s]; kc[s] = kn[s]; }
+    if (vl) vl_store(S + L.Dx + (i + 1) * VS, h, vA);
   }
   __syncthreads();
 }
 
 // ------------------------------------------------------------------ QP: Riccati factorisation
 // Backward sweep recomputing P_i, K_i, Lambda_i^-1 for R~ = R + (polish ? 0 : ll/sl + lu/su) with inputs
-// pinned by `act` eliminated in polish mode, merged with the vector recursion for the linear term rho.
-// Uses the structure A[:,0:3] = [I;0]:  with T1' = P [A|B]' (cols 3..16), the blocks of [A B]^T P [A B] are
-//   [a<3][b<3] = P[a][b],  [a<3][b>=3] = T1'[a][b-3],  [a>=3][b>=3] = F'[a-3][b-3] = sum_k AB'[k][a-3] T1'[k][b-3].
-// Returns false if a stage Hessian was not positive definite.
+// pinned by `act` eliminated in polish mode, merged with the vector recursion for the linear term rho
+// (the vector rides in pad column 14 of the second product).  Per stage, on the matrix cores:
+//   T1'' = P_{i+1} AB''            (P is kept in registers as an accumulator tile and, being symmetric,
+//   F''  = AB''^T [T1'' | p]        is fed back as the A operand)
+//   P_i  = Q + G + M^T K           with G = [A|B]^T P [A|B] restricted to states, assembled from F'', T1'', P.
+// The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
+// that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename TQ>
 __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L, bool polish) {
-  const int N = m.N, lane = threadIdx.x, nv = N * NU;
-  // ---- per-lane roles, fixed over the sweep
-  const int r4 = lane >> 2, g4 = lane & 3;                       // Ph1/Ph4: (row, 4-column group), lanes 0..51
-  int fa = 0, fg = 0;                                            // Ph2: lane -> (a', g) with 4g <= a' (32 items)
-  {
-    int cnt = 0;
-    for (int a = 0; a < 14; ++a)
-      for (int g = 0; g * 4 <= a; ++g) { if (cnt == lane) { fa = a; fg = g; } ++cnt; }
-  }
-  const int va = lane < NY ? lane : 0, vcol = va >= 3 ? va - 3 : 0, vj = va >= NX ? va - NX : 0;
-  int goff[4];   // Ph4 gather offsets for G(r, c) = ([A B]^T P [A B])[r][c], c = 4*g4 + cc
-  bool gisP[4];  // source is P_next (ping-pong base added at use)
-  int moff[4];   // M[j][r4] source
-  int m3off[4];  // Ph3 lane b < 13: M[:,b] sources
+  const int N = m.N, lane = threadIdx.x, nv = N * NU, h = lane >> 4, c = lane & 15;
+  const bool vl = c == 14;
   bool ok = true;
-  {
-    const int r = r4 < NX ? r4 : 0;
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      int c = 4 * g4 + cc;
-      if (c >= NX) c = NX - 1;
-      gisP[cc] = (r < 3 && c < 3);
-      if (r < 3 && c < 3) goff[cc] = r * ABW + c;
-      else if (r < 3) goff[cc] = L.T1 + r * ABW + (c - 3);
-      else if (c < 3) goff[cc] = L.T1 + c * ABW + (r - 3);
-      else goff[cc] = L.F + ((r > c ? r : c) - 3) * ABW + ((r > c ? c : r) - 3);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) moff[j] = r < 3 ? L.T1 + r * ABW + 10 + j : L.F + (10 + j) * ABW + (r - 3);
-    const int b = lane < NX ? lane : 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) m3off[j] = b < 3 ? L.T1 + b * ABW + 10 + j : L.F + (10 + j) * ABW + (b - 3);
-  }
-  const TQ qdiag = r4 < NX ? (TQ)(m.h * m.W[r4]) : TQ(0);
   // stage input Hessian diagonals R~ (negative value = input pinned by the polish)
   for (int i = lane; i < nv; i += 64) {
-    const TQ rr = (TQ)(m.h * m.W[NX + (i & 3)]);
+    const TQ rr = S[L.wq + 2 * VS + (i & 3)];
     TQ v;
     if (!polish) v = rr + tdiv(S[L.ll + i], S[L.sl + i]) + tdiv(S[L.lu + i], S[L.su + i]);
     else v = S[L.act + i] != TQ(0) ? TQ(-1) : rr;
     S[L.rt + i] = v;
   }
-  // P_N = W_e ; K pads
-  for (int it = lane; it < ABS; it += 64) S[L.P + it] = ((it >> 4) == (it & 15) && (it >> 4) < NX) ? (TQ)m.We[it >> 4] : TQ(0);
-  for (int it = lane; it < N * NU * 3; it += 64) S[L.K + (it / 3) * ABW + NX + it % 3] = 0;
-  TQ pv = 0;
-  TQ vc[NX], vn[NX];
-  load_col(S + L.AB + (N - 1) * ABS, vcol, vc);
+  for (int it = lane; it < N * NU * 3; it += 64) S[L.K + (it / 3) * ABW + NX + it % 3] = 0;   // K pad columns
+  const Sel<TQ> sel(h);
+  const KMaj<TQ> km(L, N, h, c);
+  // P_N = W_e as an accumulator tile: Pop[s] = P[RI(s,h)][c]; per-lane masks for the assembly of Q + G
+  TQ Pop[4], pv[4] = {0, 0, 0, 0}, qdg[4], mA2[4], mA1[4], mPo[4], mT[4];
+  int toff[4];
+  const bool cq = c < 10, cp = c >= 10 && c < NX;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = RI<TQ>(s, h);
+    const bool rq = row < 10, rp = row >= 10 && row < NX;
+    Pop[s] = (row == c && c < NX) ? S[L.wq + VS + c] : TQ(0);
+    qdg[s] = (row == c && c < NX) ? S[L.wq + c] : TQ(0);
+    mA2[s] = (cq && rq) ? TQ(1) : TQ(0);
+    mA1[s] = (cq && rp) ? TQ(1) : TQ(0);
+    mPo[s] = (cp && rp) ? TQ(1) : TQ(0);
+    mT[s] = (cp && rq) ? TQ(1) : TQ(0);
+    toff[s] = L.sT + (cp ? (c - 10) * VS : 0) + (row < VS ? row : 0);
+  }
+  // operands of the k=4 tile M^T K: M[h][c] (c < 10: F''[10+h][c]; position c: T1''[c][10+h]) and K[h][c]
+  const int moff = cq ? L.sF + h * VS + c : (cp ? L.sT + (c - 10) * VS + 10 + h : L.sF);
+  const TQ mmask = c < NX ? TQ(1) : TQ(0);
+  // which accumulator registers hold tile rows 10..13 (F'': M and Lambda rows) / 10..12 (T1'': position rows)
+  const int b3 = lane < NX ? lane : 0, vj = (lane >= NX && lane < NY) ? lane - NX : 0;
+  TQ cur[4], nxt[4];
+  km.load(S, N - 1, cur);
   __syncthreads();
   for (int i = N - 1; i >= 0; --i) {
-    const int pc = (N - 1 - i) & 1;
-    const TQ* AB = S + L.AB + i * ABS;
-    const TQ* Pn = S + L.P + pc * ABS;
-    if (i > 0) load_col(S + L.AB + (i - 1) * ABS, vcol, vn);
-    // ---- Ph1: T1' = P_{i+1} AB'   (13 x 14, 4 columns per lane) ; vector t = [A B]^T p_{i+1}
-    if (lane < 52) {
-      TQ prow[16];
+    km.load(S, i > 0 ? i - 1 : 0, nxt);
+    TQ acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const V4<TQ> v = *reinterpret_cast<const V4<TQ>*>(Pn + r4 * ABW + 4 * q);
-        prow[4 * q] = v.a; prow[4 * q + 1] = v.b; prow[4 * q + 2] = v.c; prow[4 * q + 3] = v.d;
-      }
-      TQ a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int s = 0; s < 4; ++s) mfma(acc1, Pop[s], cur[s]);              // T1''
+    TQ b2[4];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) {
-        const V4<TQ> v = *reinterpret_cast<const V4<TQ>*>(AB + k * ABW + ((g4 ^ sw(k)) << 2));
-        a0 += prow[k] * v.a; a1 += prow[k] * v.b; a2 += prow[k] * v.c; a3 += prow[k] * v.d;
+    for (int s = 0; s < 4; ++s) b2[s] = vl ? pv[s] : acc1[s];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma(acc2, cur[s], b2[s]);               // F'' ; column 14 = AB''^T p
+    // hand rows 10..13 over to the stage-Hessian lanes through LDS
+    if (sizeof(TQ) == 4) {
+      if (h >= 2) {   // h = 2: registers 2,3 = rows 10,11 ; h = 3: registers 0,1 = rows 12,13
+        const TQ f0 = h == 2 ? acc2[2] : acc2[0], f1 = h == 2 ? acc2[3] : acc2[1];
+        const TQ t0 = h == 2 ? acc1[2] : acc1[0], t1 = acc1[3];
+        const int r0 = h == 2 ? 0 : 2;
+        S[L.sF + r0 * VS + c] = f0;
+        S[L.sF + (r0 + 1) * VS + c] = f1;
+        S[L.sT + r0 * VS + c] = t0;
+        if (h == 2) S[L.sT + VS + c] = t1;
       }
-      V4<TQ> o; o.a = a0; o.b = a1; o.c = a2; o.d = a3;
-      *reinterpret_cast<V4<TQ>*>(S + L.T1 + r4 * ABW + 4 * g4) = o;
+    } else {          // row 10 + j is register in_s(j) of lane group in_h(j)
+      const TQ fv = h >= 2 ? acc2[2] : acc2[3], tvv = h >= 2 ? acc1[2] : acc1[3];
+      const int rr = h >= 2 ? h - 2 : h + 2;
+      S[L.sF + rr * VS + c] = fv;
+      if (rr < 3) S[L.sT + rr * VS + c] = tvv;
     }
-    TQ t = 0;
+    if (vl) {
+      TQ idp[4];
 #pragma unroll
-    for (int k = 0; k < NX; ++k) t += vc[k] * bc(pv, k);
-    if (va < 3) t = pv;
-    __syncthreads();
-    // ---- Ph2: F' lower block-triangle = AB'^T T1'
-    if (lane < 32) {
-      TQ a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-      for (int k = 0; k < NX; ++k) {
-        const TQ p = AB[abo(k, fa)];
-        const V4<TQ> v = *reinterpret_cast<const V4<TQ>*>(S + L.T1 + k * ABW + 4 * fg);
-        a0 += p * v.a; a1 += p * v.b; a2 += p * v.c; a3 += p * v.d;
-      }
-      V4<TQ> o; o.a = a0; o.b = a1; o.c = a2; o.d = a3;
-      *reinterpret_cast<V4<TQ>*>(S + L.F + fa * ABW + 4 * fg) = o;
+      for (int s = 0; s < 4; ++s) idp[s] = sel.P[s] * pv[s];   // identity columns: (A^T p)[p] = p[p]
+      vl_store(S + L.stv, h, idp);
+      vl_store(S + L.stv + VS, h, acc2);                         // rows 0..9: A^T p ; rows 10..13: B^T p
     }
     __syncthreads();
-    // ---- Ph3: Lambda = R~ + F_uu, Cholesky in registers (redundantly on every lane),
-    //           lanes b<13: K[:,b] = -Lambda^-1 M[:,b]; lanes 13..16: column of Lambda^-1
+    // ---- Lambda = R~ + F_uu, Cholesky in registers (redundantly on every lane),
+    //      lanes b<13: K[:,b] = -Lambda^-1 M[:,b], p_i[b]; lanes 13..16: column of Lambda^-1, k_i
     {
       TQ Lm[4][4];
       bool am[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b2 = 0; b2 <= a; ++b2) Lm[a][b2] = S[L.F + (10 + a) * ABW + 10 + b2];
+        for (int q = 0; q <= a; ++q) Lm[a][q] = S[L.sF + a * VS + 10 + q];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const TQ rt = S[L.rt + i * NU + a];
@@ -703,96 +784,85 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
       for (int a = 0; a < 4; ++a)
         if (am[a]) {
 #pragma unroll
-          for (int b2 = 0; b2 < 4; ++b2) { if (b2 < a) Lm[a][b2] = 0; if (b2 > a) Lm[b2][a] = 0; }
+          for (int q = 0; q < 4; ++q) { if (q < a) Lm[a][q] = 0; if (q > a) Lm[q][a] = 0; }
           Lm[a][a] = 1;
         }
       TQ id[4];
       bool pd = true;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        TQ d = Lm[c][c];
+      for (int cc = 0; cc < 4; ++cc) {
+        TQ d = Lm[cc][cc];
 #pragma unroll
-        for (int k = 0; k < c; ++k) d -= Lm[c][k] * Lm[c][k];
+        for (int k = 0; k < cc; ++k) d -= Lm[cc][k] * Lm[cc][k];
         if (!(d > 0)) { pd = false; d = 1; }
-        id[c] = trsqrt(d);
+        id[cc] = trsqrt(d);
 #pragma unroll
-        for (int a = c + 1; a < 4; ++a) {
-          TQ s2 = Lm[a][c];
+        for (int a = cc + 1; a < 4; ++a) {
+          TQ s2 = Lm[a][cc];
 #pragma unroll
-          for (int k = 0; k < c; ++k) s2 -= Lm[a][k] * Lm[c][k];
-          Lm[a][c] = s2 * id[c];
+          for (int k = 0; k < cc; ++k) s2 -= Lm[a][k] * Lm[cc][k];
+          Lm[a][cc] = s2 * id[cc];
         }
       }
       if (!pd) ok = false;
-      // rhs: M[:,b] for lanes < 13, e_j for lanes 13..16
+      // rhs: M[:,b] for lanes < 13 (b < 10: F''[10+j][b]; position b = 10+t: T1''[10+t][10+j]), e_j for lanes 13..16
       TQ y[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) y[c] = lane < NX ? (am[c] ? TQ(0) : S[m3off[c]]) : ((lane - NX) == c ? TQ(1) : TQ(0));
-      // forward solve G y' = y, backward solve G^T x = y'
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        TQ s2 = y[c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) s2 -= Lm[c][k] * y[k];
-        y[c] = s2 * id[c];
+      for (int j = 0; j < 4; ++j) {
+        const TQ mv = b3 < 10 ? S[L.sF + j * VS + b3] : S[L.sT + (b3 - 10) * VS + 10 + j];
+        y[j] = lane < NX ? (am[j] ? TQ(0) : mv) : ((lane - NX) == j ? TQ(1) : TQ(0));
       }
 #pragma unroll
-      for (int c = 3; c >= 0; --c) {
-        TQ s2 = y[c];
+      for (int cc = 0; cc < 4; ++cc) {
+        TQ s2 = y[cc];
 #pragma unroll
-        for (int k = c + 1; k < 4; ++k) s2 -= Lm[k][c] * y[k];
-        y[c] = s2 * id[c];
+        for (int k = 0; k < cc; ++k) s2 -= Lm[cc][k] * y[k];
+        y[cc] = s2 * id[cc];
       }
-      // vector part: gt_j on lanes 13..16, broadcast
-      TQ gt = (va >= NX) ? S[L.rho + i * NU + vj] + t : TQ(0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (va >= NX && vj == c && am[c]) gt = 0;
-      const TQ g0 = bc(gt, 13), g1 = bc(gt, 14), g2 = bc(gt, 15), g3 = bc(gt, 16);
+      for (int cc = 3; cc >= 0; --cc) {
+        TQ s2 = y[cc];
+#pragma unroll
+        for (int k = cc + 1; k < 4; ++k) s2 -= Lm[k][cc] * y[k];
+        y[cc] = s2 * id[cc];
+      }
+      // vector part: gt = rho + B^T p (masked), p_i = A^T p + K^T gt, k_i = -Lambda^-1 gt
+      TQ g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = am[j] ? TQ(0) : S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j];
       if (lane < NX) {
         TQ* Kc = S + L.K + i * KS + lane;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { if (am[c]) y[c] = 0; Kc[c * ABW] = -y[c]; }
-        pv = t - (y[0] * g0 + y[1] * g1 + y[2] * g2 + y[3] * g3);
-      } else {
-        if (lane < NY) {
-          TQ* Li = S + L.Linv + i * 16 + vj * 4;
+        for (int j = 0; j < 4; ++j) { if (am[j]) y[j] = 0; Kc[j * ABW] = -y[j]; }
+        const TQ tb = b3 < 10 ? S[L.stv + VS + b3] : S[L.stv + b3];
+        S[L.spv + lane] = tb - (y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3]);
+      } else if (lane < NY) {
+        TQ* Li = S + L.Linv + i * 16 + vj * 4;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) Li[c] = y[c];
-          TQ kvv = -(y[0] * g0 + y[1] * g1 + y[2] * g2 + y[3] * g3);
+        for (int j = 0; j < 4; ++j) Li[j] = y[j];
+        TQ kvv = -(y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (vj == c && am[c]) kvv = 0;
-          S[L.kv + i * NU + vj] = kvv;
-        }
-        pv = 0;
+        for (int j = 0; j < 4; ++j)
+          if (vj == j && am[j]) kvv = 0;
+        S[L.vin + i * VS + vj] = kvv;
+        if (lane < VS) S[L.spv + lane] = 0;
       }
     }
     if (i == 0) break;
     __syncthreads();
-    // ---- Ph4: P_i = Q + A^T P A + M^T K   (13 x 13, 4 columns per lane)
-    if (lane < 52) {
-      TQ mj[4];
+    // ---- P_i = Q + G + M^T K as one k=4 tile on top of the assembled C operand
+    {
+      const TQ mk = mmask * S[moff];
+      const TQ kk = S[L.K + i * KS + h * ABW + c];
+      TQ C4[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mj[j] = S[moff[j]];
-      TQ o[4];
+      for (int s = 0; s < 4; ++s)
+        C4[s] = mA2[s] * acc2[s] + mA1[s] * acc1[s] + mPo[s] * Pop[s] + mT[s] * S[toff[s]] + qdg[s];
+      mfma(C4, mk, kk);
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) o[cc] = S[goff[cc] + (gisP[cc] ? L.P + pc * ABS : 0)];
-      const TQ* Kr = S + L.K + i * KS + 4 * g4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const V4<TQ> kv4 = *reinterpret_cast<const V4<TQ>*>(Kr + j * ABW);
-        o[0] += mj[j] * kv4.a; o[1] += mj[j] * kv4.b; o[2] += mj[j] * kv4.c; o[3] += mj[j] * kv4.d;
-      }
-      const int cd = r4 - 4 * g4;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
-        if (cd == cc) o[cc] += qdiag;
-      V4<TQ> ov; ov.a = o[0]; ov.b = o[1]; ov.c = o[2]; ov.d = o[3];
-      *reinterpret_cast<V4<TQ>*>(S + L.P + (1 - pc) * ABS + r4 * ABW + 4 * g4) = ov;
+      for (int s = 0; s < 4; ++s) { Pop[s] = C4[s]; cur[s] = nxt[s]; }
+      vl_load(S + L.spv, h, pv);
     }
-#pragma unroll
-    for (int k = 0; k < NX; ++k) vc[k] = vn[k];
     __syncthreads();
   }
   __syncthreads();
@@ -811,7 +881,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
   for (; it < maxit; ++it) {
     TQ rdm = 0, mu = 0;
     for (int i = tid; i < nv; i += 64) {
-      rdm = tmax(rdm, tabs(S[L.grad + i] - S[L.ll + i] + S[L.lu + i]));
+      rdm = tmax(rdm, tabs(S[L.grad + GI(i)] - S[L.ll + i] + S[L.lu + i]));
       mu += S[L.sl + i] * S[L.ll + i] + S[L.su + i] * S[L.lu + i];
     }
     rdm = wave_max(rdm);
@@ -819,7 +889,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     if (!(rdm == rdm) || !(mu == mu)) { status = 1; break; }
     if (rdm <= tol * gm && mu <= tol) { status = 0; break; }
     // predictor: (H + Sigma) dza = -grad
-    for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + i];
+    for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
     const bool fok = riccati_factor(m, S, L, false);
@@ -851,7 +921,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       const TQ dl = -ll - tdiv(ll, sl) * d, du = -lu + tdiv(lu, su) * d;
       const TQ rcl = -sl * ll + sigma * mu - d * dl;
       const TQ rcu = -su * lu + sigma * mu + d * du;
-      const TQ rd = S[L.grad + i] - ll + lu;
+      const TQ rd = S[L.grad + GI(i)] - ll + lu;
       S[L.rho + i] = rd - tdiv(rcl, sl) + tdiv(rcu, su);
     }
     __syncthreads();
@@ -883,7 +953,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       S[L.z + i] += ap * d; S[L.sl + i] = sl + ap * d; S[L.su + i] = su - ap * d;
       S[L.ll + i] = ll + ad * dl; S[L.lu + i] = lu + ad * du;
     }
-    for (int i = tid; i < (N + 1) * NX; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
+    for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
     __syncthreads();
     PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
   }
@@ -917,7 +987,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     // stationarity on the free set, worst multiplier sign violation on the pinned set
     TQ gF = 0, vmax = 0;
     for (int i = tid; i < nv; i += 64) {
-      const TQ a = S[L.act + i], g = S[L.grad + i];
+      const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
       if (a == TQ(0)) gF = tmax(gF, tabs(g));
       else vmax = tmax(vmax, a < 0 ? -g : g);
     }
@@ -928,7 +998,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       // the point minimises the QP on the working set: multipliers are meaningful here only
       if (vmax > tolm) {
         for (int i = tid; i < nv; i += 64) {
-          const TQ a = S[L.act + i], g = S[L.grad + i];
+          const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
           if (a != TQ(0) && (a < 0 ? -g : g) >= vmax) S[L.act + i] = 0;  // release the worst one
         }
         refactor = true;
@@ -941,7 +1011,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
         gF_prev = gF;
       }
     }
-    for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + i];
+    for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
     if (refactor) { const bool fok = riccati_factor(m, S, L, true); PF_STOP(PF_FACTOR); if (!fok) return false; }
@@ -990,7 +1060,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
   PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
   PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
   TQ gm = 1;
-  for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + i]));
+  for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
   gm = wave_max(gm);
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = TQ(0.1) * gm / S[L.sl + i]; S[L.lu + i] = TQ(0.1) * gm / S[L.su + i]; }
   __syncthreads();
@@ -1074,7 +1144,7 @@ __device__ inline long chunk_row(int j, int have, int idx, int skip, int len) { 
 
 template <typename TQ>
 __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const DevState<TQ> st, const int mode) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+  extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = m.N, nb = m.nb, nv = N * NU;
   const Lds L = lds_layout(N, nb);
@@ -1115,7 +1185,13 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   for (int it = tid; it < (N + 1) * NX; it += 64) {
     const int i = it / NX, k = it - i * NX;
     const double q = i < N ? m.h * m.W[k] : m.We[k];
-    S[L.qv + it] = (TQ)(q * (D[L.X + it] - xref(i, k)));
+    S[L.qv + i * VS + o2i(k)] = (TQ)(q * (D[L.X + it] - xref(i, k)));
+  }
+  for (int it = tid; it < (N + 1) * 3; it += 64) S[L.qv + (it / 3) * VS + NX + it % 3] = 0;
+  if (tid < VS) {   // weights in internal order: stage, terminal, input
+    S[L.wq + tid] = tid < NX ? (TQ)(m.h * m.W[i2o(tid)]) : TQ(0);
+    S[L.wq + VS + tid] = tid < NX ? (TQ)m.We[i2o(tid)] : TQ(0);
+    S[L.wq + 2 * VS + tid] = tid < NU ? (TQ)(m.h * m.W[NX + tid]) : TQ(0);
   }
   for (int it = tid; it < nv; it += 64) {
     const int i = it >> 2, k = it & 3;
@@ -1149,13 +1225,20 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   shoot_sens(m, S, L);
   __syncthreads();
   PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
-  if (tid < NX) S[L.dx + tid] = (TQ)(D[L.x0 + tid] - D[L.X + tid]);   // dx_0 = x_meas - X_0 (lbx = ubx = x_init)
+  if (tid < VS) { S[L.dx + tid] = 0; S[L.AB + N * ABS + tid] = 0; }
+  for (int it = tid; it < N * VS; it += 64) S[L.vin + it] = 0;
+  __syncthreads();
+  if (tid < NX) S[L.dx + o2i(tid)] = (TQ)(D[L.x0 + tid] - D[L.X + tid]);   // dx_0 = x_meas - X_0 (lbx = ubx = x_init)
   __syncthreads();
   // ---- 2. QP
   int status = 0;
   const int iters = solve_qp(m, S, L, &status PF_PASS);
   // ---- 3. full step (iterate accumulated in double)
-  for (int i = tid; i < (N + 1) * NX; i += 64) { const double v = D[L.X + i] + (double)S[L.dx + i]; D[L.X + i] = v; gX[i] = v; }
+  for (int it = tid; it < (N + 1) * NX; it += 64) {
+    const int i = it / NX, k = it - i * NX;
+    const double v = D[L.X + it] + (double)S[L.dx + i * VS + o2i(k)];
+    D[L.X + it] = v; gX[it] = v;
+  }
   for (int i = tid; i < nv; i += 64) { const double v = D[L.U + i] + (double)S[L.z + i]; D[L.U + i] = v; gU[i] = v; }
   __syncthreads();
   // cost at the new iterate (get_cost)
@@ -1244,7 +1327,7 @@ __global__ void predict_kernel(const DevModel<TQ> m, const double* x, const doub
 
 template <typename TQ>
 __global__ void regress_kernel(const DevModel<TQ> m, const DevState<TQ> st, const double* vb, const double* ad) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+  extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
   const Lds L = lds_layout(m.N, m.nb);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
   const int b = blockIdx.x;
@@ -1268,7 +1351,7 @@ __global__ void plant_kernel(const DevModel<TQ> m, double* xs, const double* w, 
 
 // reduce per-instance statistics to 5 numbers (sum, sum, sum, max, #failed)
 __global__ void stats_kernel(const double* stats, const int* status, int B, double* out5) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+  extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
   double (*sh)[256] = reinterpret_cast<double (*)[256]>(smem_raw);  // [5][256]
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {

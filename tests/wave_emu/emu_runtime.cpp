@@ -20,7 +20,7 @@ std::vector<Fiber> fibers;
 ucontext_t sched_ctx;
 const std::function<void()>* body_ptr = nullptr;
 int current = -1;
-std::vector<uint64_t> exch(1024);
+std::vector<uint64_t> exch(1024), exch2(1024);
 void trampoline() {
   (*body_ptr)();
   fibers[current].done = true;
@@ -28,6 +28,7 @@ void trampoline() {
 }
 }  // namespace
 uint64_t* exchange() { return exch.data(); }
+uint64_t* exchange2() { return exch2.data(); }
 void sync() { swapcontext(&fibers[current].ctx, &sched_ctx); }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {

@@ -76,6 +76,37 @@ inline int __builtin_amdgcn_readlane(int v, int src) {
   emu::sync();
   return r;
 }
+// v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C, lane (h = lane>>4, c = lane&15)
+// holds A[c][h], B[h][c]; C/D rows: f32 4h+reg, f64 h+4reg (MI355X_MICROARCH / cdna_hip_programming.md section 3)
+namespace emu { uint64_t* exchange2(); }
+template <typename T, typename V4, bool F64>
+inline V4 emu_mfma(T a, T b, V4 c) {
+  uint64_t* ea = emu::exchange();
+  uint64_t* eb = emu::exchange2();
+  const unsigned t = emu::cur->tid.x, w = t & ~63u, l = t & 63u, h = l >> 4, col = l & 15;
+  uint64_t ra = 0, rb = 0;
+  std::memcpy(&ra, &a, sizeof(T));
+  std::memcpy(&rb, &b, sizeof(T));
+  ea[t] = ra; eb[t] = rb;
+  emu::sync();
+  for (int reg = 0; reg < 4; ++reg) {
+    const unsigned row = F64 ? h + 4 * reg : 4 * h + reg;
+    T acc = c[reg];
+    for (unsigned k = 0; k < 4; ++k) {
+      T av, bv;
+      std::memcpy(&av, &ea[w + 16 * k + row], sizeof(T));
+      std::memcpy(&bv, &eb[w + 16 * k + col], sizeof(T));
+      acc = std::fma(av, bv, acc);
+    }
+    c[reg] = acc;
+  }
+  emu::sync();
+  return c;
+}
+typedef float emu_f4 __attribute__((ext_vector_type(4)));
+typedef double emu_d4 __attribute__((ext_vector_type(4)));
+inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f4 c, int, int, int) { return emu_mfma<float, emu_f4, false>(a, b, c); }
+inline emu_d4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emu_d4 c, int, int, int) { return emu_mfma<double, emu_d4, true>(a, b, c); }
 // DPP: quad_perm (ctrl 0x00..0xFF) and row_ror:n (0x121..0x12F) with all rows/banks enabled
 inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool) {
   (void)old;
