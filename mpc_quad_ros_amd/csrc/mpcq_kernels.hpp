@@ -55,7 +55,7 @@ __device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __
 
 template <typename TQ>
 struct DevModel {
-  int N, nb, skip, Tmax, B, qp_max_iter, polish_max;
+  int N, nb, skip, Tmax, B, qp_max_iter, polish_max, warm_max;
   double h, dt_pred;
   double mass, J[3], tmax, xf[4], yf[4], zl[4], g;
   double W[NY], We[NX], ulb[NU], uub[NU], uref[NU];
@@ -690,8 +690,8 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& 
 //   P_i  = Q + G + M^T K           with G = [A|B]^T P [A|B] restricted to states, assembled from F'', T1'', P.
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
-template <typename TQ>
-__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L, bool polish) {
+template <typename TQ, bool polish>
+__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L) {
   const int N = m.N, lane = threadIdx.x, nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
@@ -727,8 +727,13 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
   const TQ mmask = c < NX ? TQ(1) : TQ(0);
   // which accumulator registers hold tile rows 10..13 (F'': M and Lambda rows) / 10..12 (T1'': position rows)
   const int b3 = lane < NX ? lane : 0, vj = (lane >= NX && lane < NY) ? lane - NX : 0;
+  const int m3off = b3 < 10 ? L.sF + b3 : L.sT + (b3 - 10) * VS + 10, m3str = b3 < 10 ? VS : 1;   // M[j][b3]
+  const int tboff = b3 < 10 ? L.stv + VS + b3 : L.stv + b3;                                       // (A^T p)[b3]
+  const int o4str = lane < NX ? ABW : 1;
+  const TQ o4sgn = lane < NX ? TQ(-1) : TQ(1), tbm = lane < NX ? TQ(1) : TQ(0);
   TQ cur[4], nxt[4];
   km.load(S, N - 1, cur);
+  if (lane < VS) S[L.spv + lane] = 0;
   __syncthreads();
   for (int i = N - 1; i >= 0; --i) {
     km.load(S, i > 0 ? i - 1 : 0, nxt);
@@ -765,11 +770,10 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
       vl_store(S + L.stv + VS, h, acc2);                         // rows 0..9: A^T p ; rows 10..13: B^T p
     }
     __syncthreads();
-    // ---- Lambda = R~ + F_uu, Cholesky in registers (redundantly on every lane),
-    //      lanes b<13: K[:,b] = -Lambda^-1 M[:,b], p_i[b]; lanes 13..16: column of Lambda^-1, k_i
+    // ---- Lambda = R~ + F_uu, Cholesky in registers (redundantly on every lane, straight-line code);
+    //      lanes b<13: K[:,b] = -Lambda^-1 M[:,b] and p_i[b]; lanes 13..16: column of Lambda^-1 and k_i
     {
-      TQ Lm[4][4];
-      bool am[4];
+      TQ Lm[4][4], mk[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -777,24 +781,28 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const TQ rt = S[L.rt + i * NU + a];
-        am[a] = rt < TQ(0);
-        Lm[a][a] += rt;
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (am[a]) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { if (q < a) Lm[a][q] = 0; if (q > a) Lm[q][a] = 0; }
-          Lm[a][a] = 1;
+        if (polish) {                      // pinned input: unit row/column, zero right-hand sides
+          mk[a] = rt < TQ(0) ? TQ(0) : TQ(1);
+          Lm[a][a] = mk[a] * (Lm[a][a] + rt) + (TQ(1) - mk[a]);
+        } else {
+          mk[a] = TQ(1);
+          Lm[a][a] += rt;
         }
+      }
+      if (polish) {
+#pragma unroll
+        for (int a = 1; a < 4; ++a)
+#pragma unroll
+          for (int q = 0; q < a; ++q) Lm[a][q] *= mk[a] * mk[q];
+      }
       TQ id[4];
-      bool pd = true;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         TQ d = Lm[cc][cc];
 #pragma unroll
         for (int k = 0; k < cc; ++k) d -= Lm[cc][k] * Lm[cc][k];
-        if (!(d > 0)) { pd = false; d = 1; }
+        if (!(d > TQ(0))) ok = false;
+        d = d > TQ(0) ? d : TQ(1);
         id[cc] = trsqrt(d);
 #pragma unroll
         for (int a = cc + 1; a < 4; ++a) {
@@ -804,13 +812,13 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
           Lm[a][cc] = s2 * id[cc];
         }
       }
-      if (!pd) ok = false;
       // rhs: M[:,b] for lanes < 13 (b < 10: F''[10+j][b]; position b = 10+t: T1''[10+t][10+j]), e_j for lanes 13..16
-      TQ y[4];
+      TQ y[4], g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const TQ mv = b3 < 10 ? S[L.sF + j * VS + b3] : S[L.sT + (b3 - 10) * VS + 10 + j];
-        y[j] = lane < NX ? (am[j] ? TQ(0) : mv) : ((lane - NX) == j ? TQ(1) : TQ(0));
+        const TQ mv = S[m3off + j * m3str];
+        y[j] = mk[j] * (lane < NX ? mv : ((lane - NX) == j ? TQ(1) : TQ(0)));
+        g[j] = mk[j] * (S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j]);   // gt = rho + B^T p
       }
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
@@ -826,26 +834,20 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
         for (int k = cc + 1; k < 4; ++k) s2 -= Lm[k][cc] * y[k];
         y[cc] = s2 * id[cc];
       }
-      // vector part: gt = rho + B^T p (masked), p_i = A^T p + K^T gt, k_i = -Lambda^-1 gt
-      TQ g[4];
+      // lanes < 13 store K[:,b] = -y and p_i[b] = (A^T p)[b] - y.gt ; lanes 13..16 store Lambda^-1[vj][:] = y and k_vj = -y.gt
+      const TQ dot = y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3];
+      const TQ tb = S[tboff];
+      if (lane < NY) {
+        TQ* o4 = S + (lane < NX ? L.K + i * KS + lane : L.Linv + i * 16 + vj * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] = am[j] ? TQ(0) : S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j];
-      if (lane < NX) {
-        TQ* Kc = S + L.K + i * KS + lane;
+        for (int j = 0; j < 4; ++j) o4[j * o4str] = o4sgn * y[j] * (polish ? mk[j] : TQ(1));
+        TQ ex = tbm * tb - dot;
+        if (polish && lane >= NX) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { if (am[j]) y[j] = 0; Kc[j * ABW] = -y[j]; }
-        const TQ tb = b3 < 10 ? S[L.stv + VS + b3] : S[L.stv + b3];
-        S[L.spv + lane] = tb - (y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3]);
-      } else if (lane < NY) {
-        TQ* Li = S + L.Linv + i * 16 + vj * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Li[j] = y[j];
-        TQ kvv = -(y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (vj == j && am[j]) kvv = 0;
-        S[L.vin + i * VS + vj] = kvv;
-        if (lane < VS) S[L.spv + lane] = 0;
+          for (int j = 0; j < 4; ++j)
+            if (vj == j) ex *= mk[j];
+        }
+        S[(lane < NX ? L.spv + lane : L.vin + i * VS + vj)] = ex;
       }
     }
     if (i == 0) break;
@@ -892,7 +894,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    const bool fok = riccati_factor(m, S, L, false);
+    const bool fok = riccati_factor<TQ, false>(m, S, L);
     PF_STOP(PF_FACTOR);
     if (!fok) { status = 4; break; }
     PF_START(); riccati_forward(m, S, L, L.dza); PF_STOP(PF_FWD);
@@ -966,16 +968,24 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename TQ>
-__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ gm, int& passes PF_ARG) {
+__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
-  for (int i = tid; i < nv; i += 64)
-    S[L.act + i] = S[L.ll + i] > S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > S[L.su + i] ? TQ(1) : TQ(0));
+  if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
+    for (int i = tid; i < nv; i += 64) {
+      S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
+      S[L.z + i] = 0;
+    }
+  } else {      // working set identified by the interior point
+    for (int i = tid; i < nv; i += 64)
+      S[L.act + i] = S[L.ll + i] > S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > S[L.su + i] ? TQ(1) : TQ(0));
+  }
   __syncthreads();
-  const TQ tolm = 64 * m.eps * gm;  // multiplier sign / stationarity
+  const TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
+  const TQ tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
   bool refactor = true, settled = false, full = false;
   TQ gF_prev = TQ(1e30);
-  for (passes = 0; passes < m.polish_max; ++passes) {
+  for (passes = 0; passes < max_passes; ++passes) {
     for (int i = tid; i < nv; i += 64) {
       const TQ a = S[L.act + i];
       if (a < 0) S[L.z + i] = S[L.lb + i];
@@ -994,18 +1004,21 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     gF = wave_max(gF);
     vmax = wave_max(vmax);
     if (!(gF == gF)) return false;
+#ifdef MPCQ_EMU_DEBUG
+    if (tid == 0) { int na = 0; for (int i = 0; i < nv; ++i) na += S[L.act + i] != TQ(0); printf("  polish pass %d warm %d full %d gF %.3e vmax %.3e tolm %.3e tols %.3e nact %d\n", passes, (int)warm, (int)full, (double)gF, (double)vmax, (double)tolm, (double)tols, na); }
+#endif
     if (full) {
       // the point minimises the QP on the working set: multipliers are meaningful here only
       if (vmax > tolm) {
         for (int i = tid; i < nv; i += 64) {
           const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
-          if (a != TQ(0) && (a < 0 ? -g : g) >= vmax) S[L.act + i] = 0;  // release the worst one
+          if (a != TQ(0) && (a < 0 ? -g : g) > tolm) S[L.act + i] = 0;   // release every wrong-signed multiplier
         }
         refactor = true;
         gF_prev = TQ(1e30);
         __syncthreads();
-      } else if (gF <= tolm || gF > TQ(0.25) * gF_prev) {
-        settled = true;  // stationary, or refinement stagnated at the rounding level
+      } else if (gF <= tols || gF > TQ(0.25) * gF_prev) {
+        settled = true;  // stationary to rounding, or the Newton refinement stagnated at the rounding level
         break;
       } else {
         gF_prev = gF;
@@ -1014,7 +1027,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    if (refactor) { const bool fok = riccati_factor(m, S, L, true); PF_STOP(PF_FACTOR); if (!fok) return false; }
+    if (refactor) { const bool fok = riccati_factor<TQ, true>(m, S, L); PF_STOP(PF_FACTOR); if (!fok) return false; }
     else { riccati_backward_vec(m, S, L, true); PF_STOP(PF_BWD); }
     refactor = false;
     PF_START(); riccati_forward(m, S, L, L.dz); PF_STOP(PF_FWD);
@@ -1026,17 +1039,23 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       if (d > 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.ub + i] - z) / d));
     }
     alpha = wave_min(alpha);
+    // full Newton step; if it leaves the box, clip and pin EVERY violator at once (the minimiser on a working
+    // set does not depend on the starting point, so only the sequence of working sets matters)
     int nblk = 0;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
-      const TQ d = S[L.dz + i], z = S[L.z + i] + alpha * d;
-      S[L.z + i] = z;
+      const TQ lb = S[L.lb + i], ub = S[L.ub + i];
+      TQ z = S[L.z + i] + S[L.dz + i];
       if (alpha < TQ(1)) {
-        if (d < 0 && z <= S[L.lb + i] + tolb) { S[L.act + i] = -1; nblk += 1; }
-        else if (d > 0 && z >= S[L.ub + i] - tolb) { S[L.act + i] = 1; nblk += 1; }
+        if (z <= lb + tolb) { z = lb; S[L.act + i] = -1; nblk += 1; }
+        else if (z >= ub - tolb) { z = ub; S[L.act + i] = 1; nblk += 1; }
       }
+      S[L.z + i] = z;
     }
     nblk = wave_sum(nblk);
+#ifdef MPCQ_EMU_DEBUG
+    if (tid == 0) printf("     alpha %.6e nblk %d\n", (double)alpha, nblk);
+#endif
     full = nblk == 0;
     if (nblk > 0) refactor = true;
     __syncthreads();
@@ -1044,12 +1063,33 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
   return settled;
 }
 
-// Box-QP solve: IPM to the hand-over tolerance, then active-set polish; if the polish does not
-// settle (degenerate cycling), fall back to IPM iterations down to the final tolerance.
-// On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory; returns passes.
+// Box-QP solve.  (1) Warm active-set attempt: the RTI iterate is persisted, so the working set of the
+// previous control step (inputs sitting exactly on a bound) is usually still optimal or off by one or two
+// inputs; a few passes of the active-set method from z = 0 then end on the exact KKT point at the cost of
+// about one factorisation.  (2) Otherwise (cold start, large changes, degenerate cycling): Mehrotra IPM to
+// the hand-over tolerance, then the active-set polish from the IPM's working set; if that does not settle
+// either, IPM iterations down to the final tolerance.  The QP is strictly convex, so every branch ends on
+// the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
+// returns passes (+1000 when the warm attempt had to fall back).
 template <typename TQ>
-__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* status PF_ARG) {
+__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* status, const bool try_warm PF_ARG) {
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
+  int it = 0, passes = 0, wpasses = 0;
+  TQ gm = 1;
+  if (try_warm && m.warm_max > 0) {
+    for (int i = tid; i < nv; i += 64) S[L.z + i] = 0;
+    __syncthreads();
+    PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+    for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
+    gm = wave_max(gm);
+    if (polish(m, S, L, gm, wpasses, true, m.warm_max PF_PASS)) {
+      PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+      *status = 0;
+      return wpasses;
+    }
+    wpasses += 1000;
+  }
   // interior start
   for (int i = tid; i < nv; i += 64) {
     const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
@@ -1059,17 +1099,16 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
   __syncthreads();
   PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
   PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
-  TQ gm = 1;
+  gm = 1;
   for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
   gm = wave_max(gm);
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = TQ(0.1) * gm / S[L.sl + i]; S[L.lu + i] = TQ(0.1) * gm / S[L.su + i]; }
   __syncthreads();
-  int it = 0, passes = 0;
   int st = ipm_run(m, S, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
-    if (!polish(m, S, L, gm, passes PF_PASS)) {
+    if (!polish(m, S, L, gm, passes, false, m.polish_max PF_PASS)) {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
       PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
@@ -1079,7 +1118,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
   }
   PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);   // state trajectory of the returned z
   *status = st;
-  return it + passes;
+  return it + passes + wpasses;
 }
 
 // ------------------------------------------------------------------ RGP regress (3 axes, one new point each)
@@ -1232,14 +1271,18 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  const int iters = solve_qp(m, S, L, &status PF_PASS);
+  const int iters = solve_qp(m, S, L, &status, st.qp_iter[b] > 0 PF_PASS);
   // ---- 3. full step (iterate accumulated in double)
   for (int it = tid; it < (N + 1) * NX; it += 64) {
     const int i = it / NX, k = it - i * NX;
     const double v = D[L.X + it] + (double)S[L.dx + i * VS + o2i(k)];
     D[L.X + it] = v; gX[it] = v;
   }
-  for (int i = tid; i < nv; i += 64) { const double v = D[L.U + i] + (double)S[L.z + i]; D[L.U + i] = v; gU[i] = v; }
+  for (int i = tid; i < nv; i += 64) {
+    double v = D[L.U + i] + (double)S[L.z + i];
+    v = tmin(tmax(v, m.ulb[i & 3]), m.uub[i & 3]);   // the QP keeps du inside [lb, ub]; removes the rounding of TQ -> double
+    D[L.U + i] = v; gU[i] = v;
+  }
   __syncthreads();
   // cost at the new iterate (get_cost)
   double cst = 0;

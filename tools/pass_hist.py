@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Diagnostic: histogram of QP passes per quad-step on the bench workload (uses libmpcq.so)."""
+import os, sys, collections
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mpc_quad_ros_amd.engine import Engine
+from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+from mpc_quad_ros_amd.trajectories import swarm_trajectories
+prec = 1 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else 0
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 220
+B, N, nb = 1024, 20, 10
+e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=prec))
+traj, lens = swarm_trajectories(2026, 0, B)
+e.set_trajectories(traj, lens)
+e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
+hist = collections.Counter(); permax = []; kt = []
+for k in range(steps):
+    e.sim_steps(1, 2, 5e-3)
+    it = e.get_qp_iter()
+    hist.update(it.tolist()); permax.append(int(it.max())); kt.append(e.get_kernel_time()[0])
+    if k > 0 and (it >= 1000).any() and len(sys.argv) > 3: print('fallback step', k, 'quads', np.nonzero(it >= 1000)[0].tolist(), it[it >= 1000].tolist())
+    if (e.get_status() != 0).any(): print("step", k, "failed instances", np.nonzero(e.get_status())[0], e.get_status()[e.get_status() != 0], it[e.get_status() != 0])
+tot = sum(hist.values())
+print("passes histogram (value: share):", {k: round(v / tot, 5) for k, v in sorted(hist.items())})
+fb = sum(v for k, v in hist.items() if k >= 1000)
+print("fallback share", fb / tot, "steps with >=1 fallback", sum(1 for m in permax if m >= 1000), "of", steps)
+kt = np.array(kt) * 1e3
+print("kernel ms: mean %.3f  with-fallback mean %.3f  no-fallback mean %.3f" % (kt.mean(), kt[np.array(permax) >= 1000].mean() if any(m >= 1000 for m in permax) else 0, kt[np.array(permax) < 1000].mean()))
