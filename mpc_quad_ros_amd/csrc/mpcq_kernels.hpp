@@ -544,14 +544,17 @@ __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, const Lds& L, int d
   __syncthreads();
   const Sel<TQ> sel(h);
   const RMaj<TQ> rm(L, N, L.AB, ABS, NX, h, c);
-  TQ vA[4], cur[4], nxt[4];
+  TQ vA[4], cur[4], nxt[4], zv[4], cv[4], zn[4], cn[4];
   vl_load(S + dxo, h, vA);
   rm.load(S, 0, cur);
+  vl_load(S + L.vin, h, zv);
+  vl_load(S + L.c, h, cv);
   for (int i = 0; i < N; ++i) {
-    rm.load(S, i + 1 < N ? i + 1 : i, nxt);
-    TQ zv[4], cv[4], vB[4], acc[4];
-    vl_load(S + L.vin + i * VS, h, zv);
-    vl_load(S + L.c + i * VS, h, cv);
+    const int ip = i + 1 < N ? i + 1 : i;
+    rm.load(S, ip, nxt);
+    vl_load(S + L.vin + ip * VS, h, zn);
+    vl_load(S + L.c + ip * VS, h, cn);
+    TQ vB[4], acc[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       vB[s] = sel.A[s] * vA[s] + sel.U[s] * zv[s];
@@ -560,7 +563,7 @@ __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, const Lds& L, int d
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc, cur[s], vB[s]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; cur[s] = nxt[s]; }
+    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; cur[s] = nxt[s]; zv[s] = zn[s]; cv[s] = cn[s]; }
     if (vl) vl_store(S + dxo + (i + 1) * VS, h, vA);
   }
   __syncthreads();
@@ -649,15 +652,17 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& 
   const bool vl = c == 14;
   const Sel<TQ> sel(h);
   const RMaj<TQ> rm(L, N, L.AB, ABS, NX, h, c), rk(L, N, L.K, KS, NU, h, c);
-  TQ vA[4] = {0, 0, 0, 0}, ac[4], an[4], kc[4], kn[4];
+  TQ vA[4] = {0, 0, 0, 0}, ac[4], an[4], kc[4], kn[4], kv[4], kvn[4];
   if (lane < VS) S[L.Dx + lane] = 0;
   rm.load(S, 0, ac);
   rk.load(S, 0, kc);
+  vl_load(S + L.vin, h, kv);
   for (int i = 0; i < N; ++i) {
-    rm.load(S, i + 1 < N ? i + 1 : i, an);
-    rk.load(S, i + 1 < N ? i + 1 : i, kn);
-    TQ kv[4], acc[4];
-    vl_load(S + L.vin + i * VS, h, kv);
+    const int ip = i + 1 < N ? i + 1 : i;
+    rm.load(S, ip, an);
+    rk.load(S, ip, kn);
+    vl_load(S + L.vin + ip * VS, h, kvn);
+    TQ acc[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[s] = sel.K[s] * kv[s];
 #pragma unroll
@@ -675,7 +680,7 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& 
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc, ac[s], vB[s]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; ac[s] = an[s]; kc[s] = kn[s]; }
+    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; ac[s] = an[s]; kc[s] = kn[s]; kv[s] = kvn[s]; }
     if (vl) vl_store(S + L.Dx + (i + 1) * VS, h, vA);
   }
   __syncthreads();
@@ -969,6 +974,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename TQ>
 __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+  bool fresh = warm;   // warm start: z = 0 pins nothing new (pinned inputs have bound 0), caller's dx / grad are current
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
     for (int i = tid; i < nv; i += 64) {
@@ -992,8 +998,11 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       else if (a > 0) S[L.z + i] = S[L.ub + i];
     }
     __syncthreads();
-    PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-    PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+    if (!fresh) {
+      PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+      PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+    }
+    fresh = false;
     // stationarity on the free set, worst multiplier sign violation on the pinned set
     TQ gF = 0, vmax = 0;
     for (int i = tid; i < nv; i += 64) {
@@ -1083,8 +1092,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
     PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
     for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
     gm = wave_max(gm);
-    if (polish(m, S, L, gm, wpasses, true, m.warm_max PF_PASS)) {
-      PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    if (polish(m, S, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // settles right after a rollout of the final z
       *status = 0;
       return wpasses;
     }
@@ -1105,10 +1113,12 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = TQ(0.1) * gm / S[L.sl + i]; S[L.lu + i] = TQ(0.1) * gm / S[L.su + i]; }
   __syncthreads();
   int st = ipm_run(m, S, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+  bool need_roll = true;
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
-    if (!polish(m, S, L, gm, passes, false, m.polish_max PF_PASS)) {
+    if (polish(m, S, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
+    else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
       PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
@@ -1116,7 +1126,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
       st = ipm_run(m, S, L, m.qp_tol, gm, it PF_PASS);
     }
   }
-  PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);   // state trajectory of the returned z
+  if (need_roll) { PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
   *status = st;
   return it + passes + wpasses;
 }
