@@ -38,14 +38,15 @@ def algorithmic_bytes(N, nb, itemsize):
     return itemsize * (13 * N + 2 * (17 * N + 13) + 6 * nb + 6 * nb * nb + 45)
 
 
-def algorithmic_flops(N, nb, ipm_it):
-    """Dense counts of the implemented algorithm per quad per step:
-    shooting N*(4*(2*60*14) + 4*(150+30*nb)), Riccati factorisation per IPM/polish pass
-    N*2*(13*13*17 + 153*13 + 52*4 + 91*4), vector sweeps 4*N*2*(17*13+4*13), RGP 3*8*nb^2."""
+def algorithmic_flops(N, nb, passes):
+    """Useful flops of the implemented algorithm per quad per step: shooting
+    N*(4*2*60*14 + 4*(150+30*nb)); per QP pass one Riccati factorisation N*2*(13*13*14 + 14*15/2*13 +
+    13*13*4 + 60) and four vector sweeps 4*N*2*(13*14+4*13); RGP 3*8*nb^2.  (The matrix-core tiles
+    execute 9*2048 + 16*2048 padded flops per stage and pass; only the useful ones are counted.)"""
     shoot = N * (4 * 2 * 60 * 14 + 4 * (150 + 30 * nb))
-    fact = N * 2 * (13 * 13 * 17 + 153 * 13 + 52 * 4 + 91 * 4)
-    vec = 4 * N * 2 * (17 * 13 + 4 * 13)
-    return shoot + ipm_it * (fact + vec) + 24 * nb * nb
+    fact = N * 2 * (13 * 13 * 14 + 105 * 13 + 13 * 13 * 4 + 60)
+    vec = 4 * N * 2 * (13 * 14 + 4 * 13)
+    return shoot + passes * (fact + vec) + 24 * nb * nb
 
 
 def make_engine(B, N, nb, precision, device, first_index, seed):
@@ -100,7 +101,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="quadrotors per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--nb", type=int, default=10)
-    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
+                    help="arithmetic of the QP solve (state and QP data are always formed in double)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short secondary run in the other precision")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -154,7 +157,7 @@ def main():
         k_avg = ktime / max(klaunch, 1)
         bytes_launch = algorithmic_bytes(N, nb, itemsize) * B
         achieved = bytes_launch / k_avg / 1e9
-        flops_launch = algorithmic_flops(N, nb, float(its.mean())) * B
+        flops_launch = algorithmic_flops(N, nb, float((its % 1000).mean())) * B
         out = {
             "metric": "batched MPC+RGP control steps/sec (N=20 horizon)" if N == 20 else f"batched MPC+RGP control steps/sec (N={N} horizon)",
             "value": value, "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -173,10 +176,33 @@ def main():
                          "vector_flops": {"achieved_tflops": flops_launch / k_avg / 1e12,
                                           "peak_tflops": FP_VECTOR_PEAK[args.precision],
                                           "frac": flops_launch / k_avg / 1e12 / FP_VECTOR_PEAK[args.precision]}},
-            "solver": {"mean_ipm_plus_polish_passes": float(its.mean()), "max": int(its.max()), "failed": int((status != 0).sum())},
+            "solver": {"mean_qp_passes": float((its % 1000).mean()), "max_qp_passes": int((its % 1000).max()),
+                       "ipm_fallbacks_last_step": int((its >= 1000).sum()), "failed": int((status != 0).sum())},
             "tracking": {"rms_pos_m": float(np.sqrt(stats[0] / (3 * max(stats[2], 1)))), "steps": float(stats[2]),
                          "max_pos_err_m": float(np.sqrt(stats[3])), "failed_instances": float(stats[4])},
         }
+        pmc = os.path.join(ROOT, "profiles", f"r1_pmc_traffic_{args.precision}.json")
+        if os.path.exists(pmc):   # HBM bytes per launch from rocprofv3 --pmc passes of this same command (profiles/README.md)
+            with open(pmc) as f:
+                t = json.load(f)
+            out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+            out["roofline"]["traffic_source"] = t.get("source")
+        if world == 1 and not args.no_alt:
+            e.close()
+            alt = "f32" if args.precision == "f64" else "f64"
+            e2, _ = make_engine(B, N, nb, PRECISION_F32 if alt == "f32" else PRECISION_F64, local_rank, 0, args.seed)
+            e2.sim_steps(args.warmup, n_sub, 5e-3)
+            e2.lib.mpcq_synchronize(e2.h)
+            ta = time.perf_counter()
+            e2.sim_steps(args.steps, n_sub, 5e-3)
+            e2.lib.mpcq_synchronize(e2.h)
+            tb = time.perf_counter()
+            k2, l2 = e2.get_kernel_time()
+            out["alt_precision"] = {"dtype": alt, "value": B * args.steps / (tb - ta), "unit": "control steps/s",
+                                    "kernel_avg_ms": 1e3 * k2 / max(l2, 1),
+                                    "note": "same workload with the QP arithmetic in the other precision (f32: 4 quadrotors resident per CU, "
+                                            "parity ~1e-5 typical / 1e-4 worst; f64: 2 per CU, parity ~1e-10)"}
+            e2.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, nb, args.seed)
         print(json.dumps(out))
