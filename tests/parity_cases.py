@@ -12,7 +12,7 @@ from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspac
 from mpc_quad_ros_amd.trajectories import swarm_trajectories
 from oracle.oracle import OracleEngine
 
-TOL_TF = {0: 1e-7, 1: 1e-4}     # teacher-forced, by precision code
+TOL_TF = {0: 1e-7, 1: 2e-4}     # teacher-forced, by precision code (f32: 1e-4 budget with 2x slack for weakly active bounds)
 TOL_FREE = {0: 1e-6, 1: 1e-3}
 
 

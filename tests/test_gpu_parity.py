@@ -69,6 +69,19 @@ def test_long_horizon_config5_shape():
     assert worst < 1e-4
 
 
+@pytest.mark.parametrize("name,K", [("log_traj1_v10_a10_gp0.npz", 60), ("log_traj0_v10_a10_gp2.npz", 60)])
+def test_f32_qp_mode_teacher_forced(name, K):
+    """Fast mode (QP arithmetic in float, state / QP data in double): tolerance 1e-4 relative (north_star)."""
+    worst = pc.case_teacher_forced_log(make, name, K, precision=1, check_rgp=False)
+    print(name, "f32 worst relative control deviation", worst)
+
+
+def test_f32_qp_mode_swarm_closed_loop():
+    worst = pc.case_swarm_closed_loop(make, B=64, N=20, nb=10, K=40, precision=1)
+    print("f32 swarm worst", worst)
+    assert worst < 1e-4
+
+
 def test_full_batch_properties():
     """BASELINE config 2 at full size (B=1024): size-independent properties instead of the oracle:
     permutation equivariance over instances, determinism, bounds, bit-exact cursor bookkeeping."""
