@@ -274,9 +274,10 @@ template <typename T> struct QC {
 // f(x,u) of the OCP model (src/quad_opt.py:186-251 in the reference); when `sub` != nullptr also
 // writes the record the sensitivity pass needs: x(13) | d vdot/dq (3x4) | d vdot/dv (3x3) | R[:,2].
 // GP term: m_d(s) = sum_j alpha_dj sf2 exp(-(s - X_j)^2 L2inv / 2), alpha = Kx^-1 mu.
+// gd >= 0: this lane sums only GP axis gd and the three lanes of a stage exchange the sums through gx (LDS).
 template <typename T, typename TG>
 __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const TG* sf2, const T* x, const T* u,
-                                  const TG* alpha, const TG* basis, T* f, T* sub) {
+                                  const TG* alpha, const TG* basis, T* f, T* sub, int gd = -1, TG* gx = nullptr) {
   const T* q = x + 3; const T* v = x + 7; const T* r = x + 10;
   T R[9];
   rotmat(q, R);
@@ -299,17 +300,35 @@ __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const
     T vb[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) vb[i] = R[i] * v[0] + R[3 + i] * v[1] + R[6 + i] * v[2];
-    for (int d = 0; d < 3; ++d) {
+    if (gd < 0) {
+      for (int d = 0; d < 3; ++d) {
+        TG s0 = 0, s1 = 0;
+        const TG vbd = (TG)vb[d];
+        for (int j = 0; j < nb; ++j) {
+          const TG dlt = vbd - basis[d * nb + j];
+          const TG k = alpha[d * nb + j] * sf2[d] * texp(TG(-0.5) * dlt * dlt * L2inv[d]);
+          s0 += k;
+          s1 -= k * dlt;
+        }
+        mg[d] = (T)s0;
+        mp[d] = (T)(s1 * L2inv[d]);
+      }
+    } else {
       TG s0 = 0, s1 = 0;
-      const TG vbd = (TG)vb[d];
+      const TG vbd = gd == 0 ? (TG)vb[0] : (gd == 1 ? (TG)vb[1] : (TG)vb[2]);
+      const TG l2 = L2inv[gd], sf = sf2[gd];
       for (int j = 0; j < nb; ++j) {
-        const TG dlt = vbd - basis[d * nb + j];
-        const TG k = alpha[d * nb + j] * sf2[d] * texp(TG(-0.5) * dlt * dlt * L2inv[d]);
+        const TG dlt = vbd - basis[gd * nb + j];
+        const TG k = alpha[gd * nb + j] * sf * texp(TG(-0.5) * dlt * dlt * l2);
         s0 += k;
         s1 -= k * dlt;
       }
-      mg[d] = (T)s0;
-      mp[d] = (T)(s1 * L2inv[d]);
+      gx[gd] = s0;
+      gx[3 + gd] = s1 * l2;
+      __syncthreads();
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { mg[d] = (T)gx[d]; mp[d] = (T)gx[3 + d]; }
+      __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) f[7 + i] += R[3 * i] * mg[0] + R[3 * i + 1] * mg[1] + R[3 * i + 2] * mg[2];
@@ -419,35 +438,44 @@ __device__ inline void plant_rk4(const M& m, double* x, const double* uin, doubl
 }
 
 // ------------------------------------------------------------------ shooting
-// pass 1: lane per interval, 4 RK substages in TQ; writes records + gap c_i = Phi_i - X_{i+1}
+// pass 1: lane (triple) per interval, 4 RK substages in TQ; writes records + gap c_i = Phi_i - X_{i+1}
 // (the part X_i - X_{i+1} of the gap is formed in double)
 template <typename TQ>
 __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, const Lds& L, bool gp) {
-  const int N = m.N;
+  const int N = m.N, lane = threadIdx.x;
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
-  for (int i = threadIdx.x; i < N; i += 64) {
+  // with the GP in the model the three axis sums (nb exps each) of a stage go to three neighbouring lanes
+  const int per = gp ? 3 : 1, lanes_used = gp ? 63 : 64, spr = lanes_used / per;   // stages per round
+  TQ* gx = S + L.AB + (lane / 3) * 8;   // exchange scratch: AB'' is not written before shoot_sens
+  for (int base = 0; base < N; base += spr) {
+    const int il = lane / per, d = lane - il * per;
+    const bool valid = lane < lanes_used && base + il < N;
+    const int i = valid ? base + il : 0;
+    const int gd = gp ? (lane < lanes_used ? d : 0) : -1;
     TQ x[NX], u[NU], k[NX], xt[NX], acc[NX];
 #pragma unroll
     for (int j = 0; j < NX; ++j) x[j] = (TQ)D[L.X + i * NX + j];
 #pragma unroll
     for (int j = 0; j < NU; ++j) u[j] = (TQ)D[L.U + i * NU + j];
     const TQ* al = gp ? S + L.alpha : nullptr;
-    TQ* sub = S + L.sub + i * SUBS;
-    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, x, u, al, S + L.basis, k, sub);
+    TQ* sub = (valid && d == 0) ? S + L.sub + i * SUBS : nullptr;
+    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, x, u, al, S + L.basis, k, sub, gd, gx);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = x[j] + h / 2 * k[j]; }
-    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub + SUBW);
+    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + SUBW : nullptr, gd, gx);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] += 2 * k[j]; xt[j] = x[j] + h / 2 * k[j]; }
-    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub + 2 * SUBW);
+    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + 2 * SUBW : nullptr, gd, gx);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] += 2 * k[j]; xt[j] = x[j] + h * k[j]; }
-    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub + 3 * SUBW);
+    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + 3 * SUBW : nullptr, gd, gx);
+    if (valid && d == 0) {
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const double gap = (D[L.X + i * NX + j] - D[L.X + (i + 1) * NX + j]) + (double)(h / 6 * (acc[j] + k[j]));
-      S[L.c + i * VS + o2i(j)] = (TQ)gap;
+      for (int j = 0; j < NX; ++j) {
+        const double gap = (D[L.X + i * NX + j] - D[L.X + (i + 1) * NX + j]) + (double)(h / 6 * (acc[j] + k[j]));
+        S[L.c + i * VS + o2i(j)] = (TQ)gap;
+      }
     }
   }
 }
@@ -990,28 +1018,39 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
   const TQ tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
   bool refactor = true, settled = false, full = false;
+  int nact = 1;   // pinned inputs in the working set (unknown before the first count)
   TQ gF_prev = TQ(1e30);
   for (passes = 0; passes < max_passes; ++passes) {
-    for (int i = tid; i < nv; i += 64) {
-      const TQ a = S[L.act + i];
-      if (a < 0) S[L.z + i] = S[L.lb + i];
-      else if (a > 0) S[L.z + i] = S[L.ub + i];
-    }
-    __syncthreads();
-    if (!fresh) {
-      PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    if (full) {
+      // the last pass took a full Newton step with an unchanged working set: the state trajectory is affine in z
+      for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
+      __syncthreads();
+      if (sizeof(TQ) == 8 && nact == 0) { settled = true; break; }   // no multipliers to check, step exact to f64 rounding
       PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+    } else {
+      for (int i = tid; i < nv; i += 64) {
+        const TQ a = S[L.act + i];
+        if (a < 0) S[L.z + i] = S[L.lb + i];
+        else if (a > 0) S[L.z + i] = S[L.ub + i];
+      }
+      __syncthreads();
+      if (!fresh) {
+        PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+        PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+      }
     }
     fresh = false;
     // stationarity on the free set, worst multiplier sign violation on the pinned set
     TQ gF = 0, vmax = 0;
+    int na = 0;
     for (int i = tid; i < nv; i += 64) {
       const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
       if (a == TQ(0)) gF = tmax(gF, tabs(g));
-      else vmax = tmax(vmax, a < 0 ? -g : g);
+      else { vmax = tmax(vmax, a < 0 ? -g : g); na += 1; }
     }
     gF = wave_max(gF);
     vmax = wave_max(vmax);
+    nact = wave_sum(na);
     if (!(gF == gF)) return false;
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) { int na = 0; for (int i = 0; i < nv; ++i) na += S[L.act + i] != TQ(0); printf("  polish pass %d warm %d full %d gF %.3e vmax %.3e tolm %.3e tols %.3e nact %d\n", passes, (int)warm, (int)full, (double)gF, (double)vmax, (double)tolm, (double)tols, na); }
@@ -1068,6 +1107,9 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     full = nblk == 0;
     if (nblk > 0) refactor = true;
     __syncthreads();
+  }
+  if (settled && sizeof(TQ) == 4) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
+    PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
   }
   return settled;
 }
