@@ -122,11 +122,31 @@ def main():
     prec = PRECISION_F64 if args.precision == "f64" else PRECISION_F32
     itemsize = 8 if prec == PRECISION_F64 else 4
     e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed)
+    stats_reduce = "single"
     if world > 1:
-        import torch
-        uid = [e.comm_unique_id() if rank == 0 else None]
+        # the only collective of the path: RCCL all-reduce of the 5-number swarm statistic inside libmpcq.so.
+        # If RCCL cannot be brought up on this node the statistic is reduced over the host group instead
+        # (and the bench line says so); the timed region has no collective either way.
+        stats_reduce = "rccl"
+        try:
+            uid = [e.comm_unique_id() if rank == 0 else None]
+        except Exception as ex:          # noqa: BLE001
+            uid = [f"ERR {ex}"]
         dist.broadcast_object_list(uid, src=0)
-        e.comm_init(rank, world, uid[0])
+        ok = 1
+        if isinstance(uid[0], (bytes, bytearray)):
+            try:
+                e.comm_init(rank, world, uid[0])
+            except Exception as ex:      # noqa: BLE001
+                ok = 0
+                print(f"# rank {rank}: RCCL init failed: {ex}", file=sys.stderr)
+        else:
+            ok = 0
+        import torch
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            stats_reduce = "gloo (RCCL unavailable)"
 
     def barrier():
         e.lib.mpcq_synchronize(e.h)          # hipStreamSynchronize on the engine's stream (the only one used)
@@ -149,7 +169,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    stats = e.allreduce_tracking_stats() if world > 1 else e.get_tracking_stats()
+    if world > 1 and stats_reduce == "rccl":
+        stats = e.allreduce_tracking_stats()
+    else:
+        stats = e.get_tracking_stats()
+        if world > 1:
+            import torch
+            ssum = torch.tensor([stats[0], stats[1], stats[2], 0.0, stats[4]], dtype=torch.float64)
+            smax = torch.tensor([stats[3]], dtype=torch.float64)
+            dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+            dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+            stats = ssum.numpy().copy()
+            stats[3] = float(smax[0])
 
     if rank == 0:
         total_steps = B * world * args.steps
@@ -166,7 +197,8 @@ def main():
             "config": {"workload": f"BASELINE configs[1] per GPU: batch {B} hummingbird quadrotors, N={N}, RGP {nb} basis pts/axis, "
                                    "closed loop with on-device drag plant, seeded random-waypoint references (v_max=a_max=12)",
                        "batch_per_gpu": B, "global_batch": B * world, "horizon_nodes": N, "rgp_basis": nb,
-                       "parallelism": f"shard{world}" if world > 1 else "single", "threads_per_quad": e_threads()},
+                       "parallelism": f"shard{world}" if world > 1 else "single", "threads_per_quad": 64,
+                       "stats_reduce": stats_reduce},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": f"mpcq::step_kernel<{'double' if prec == PRECISION_F64 else 'float'}>",
@@ -209,11 +241,6 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def e_threads():
-    t = os.environ.get("MPCQ_THREADS", "64")
-    return int(t) if t in ("64", "128", "256") else 64
 
 
 if __name__ == "__main__":

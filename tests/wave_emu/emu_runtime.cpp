@@ -69,7 +69,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 
 struct emuEvent { std::chrono::steady_clock::time_point t; };
 const char* hipGetErrorString(hipError_t) { return "emu"; }
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 8; return hipSuccess; }   // pretend an 8-GPU node so multi-rank tests can use LOCAL_RANK as the ordinal
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
