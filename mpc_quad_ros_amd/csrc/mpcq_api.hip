@@ -203,7 +203,7 @@ struct EngineT : mpcq_engine {
     m.polish_max = f32 ? 12 : 8;
     if (const char* t = getenv("MPCQ_IPM_TOL")) m.ipm_tol = (T)atof(t);
     if (const char* t = getenv("MPCQ_POLISH_MAX")) m.polish_max = atoi(t);
-    m.warm_max = f32 ? 10 : 8;   // passes of the warm active-set attempt before falling back to the IPM
+    m.warm_max = f32 ? 12 : 12;   // passes of the warm active-set attempt before falling back to the IPM
     if (const char* t = getenv("MPCQ_WARM_MAX")) m.warm_max = atoi(t);
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;
     m.h = c.T / c.N; m.dt_pred = c.dt_pred;

@@ -1019,6 +1019,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
   bool refactor = true, settled = false, full = false;
   int nact = 1;   // pinned inputs in the working set (unknown before the first count)
+  bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
   TQ gF_prev = TQ(1e30);
   for (passes = 0; passes < max_passes; ++passes) {
     if (full) {
@@ -1060,9 +1061,11 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       if (vmax > tolm) {
         for (int i = tid; i < nv; i += 64) {
           const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
-          if (a != TQ(0) && (a < 0 ? -g : g) > tolm) S[L.act + i] = 0;   // release every wrong-signed multiplier
+          const TQ v = a < 0 ? -g : g;
+          if (a != TQ(0) && (careful ? v >= vmax : v > tolm)) S[L.act + i] = 0;   // release wrong-signed multipliers (all, or the worst)
         }
         refactor = true;
+        released = true;
         gF_prev = TQ(1e30);
         __syncthreads();
       } else if (gF <= tols || gF > TQ(0.25) * gF_prev) {
@@ -1105,7 +1108,8 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     if (tid == 0) printf("     alpha %.6e nblk %d\n", (double)alpha, nblk);
 #endif
     full = nblk == 0;
-    if (nblk > 0) refactor = true;
+    if (nblk > 0) { refactor = true; if (released) careful = true; }
+    released = false;
     __syncthreads();
   }
   if (settled && sizeof(TQ) == 4) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
