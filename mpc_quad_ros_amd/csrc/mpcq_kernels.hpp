@@ -1182,7 +1182,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
 //   J = k* Kx^-1 ; mu_p = J mu ; Cp = sf2 - J k* + J C J^T ; G = C J^T/(Cp + sn2) ;
 //   mu += G (y - mu_p) ; C -= G (J C)      (not symmetrised, as in the reference)
 template <typename TQ>
-__device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu, TQ* gC, const double* vb, const double* ad) {
+__device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu, TQ* gC, const double* vb, const double* ad, bool c_staged = false) {
   const int n = m.nb, tid = threadIdx.x, NT = blockDim.x, n3 = 3 * n, nn = n * n;
   TQ* C = S + L.rgp;
   TQ* ks = C + al4(3 * nn);
@@ -1191,7 +1191,8 @@ __device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, T
   TQ* CJ = JC + al4(n3);
   TQ* mu = CJ + al4(n3);
   TQ* sc = mu + al4(n3);
-  for (int i = tid; i < 3 * nn; i += NT) C[i] = gC[i];
+  if (!c_staged)
+    for (int i = tid; i < 3 * nn; i += NT) C[i] = gC[i];
   for (int i = tid; i < n3; i += NT) {
     const int d = i / n;
     const TQ dl = (TQ)vb[d] - m.basis[i];
@@ -1252,12 +1253,10 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   const unsigned long long t_begin = __builtin_readcyclecounter();
   pf.t = t_begin;
 #endif
-  // ---- load persistent state (lane-contiguous records)
+  // ---- load persistent state (lane-contiguous records) and form the QP data in double.  All global
+  //      loads of a block are issued before the first use so their latencies overlap.
   double* gX = st.X + (size_t)b * (N + 1) * NX;
   double* gU = st.U + (size_t)b * N * NU;
-  for (int i = tid; i < (N + 1) * NX; i += 64) D[L.X + i] = gX[i];
-  for (int i = tid; i < nv; i += 64) D[L.U + i] = gU[i];
-  if (tid < NX) D[L.x0 + tid] = st.x_meas[(size_t)b * NX + tid];
   const int idx = st.idx[b];
   int have = 0, len = 1;
   const double* tr = nullptr;
@@ -1275,12 +1274,46 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
     return i < N ? gy[i * NY + k] : gyN[k];
   };
   auto uref = [&](int i, int k) -> double { return (mode & MODE_TRAJ) ? m.uref[k] : gy[i * NY + NX + k]; };
-  __syncthreads();
-  // QP data formed in double: qv = Q_i (X_i - xref_i), r0 = R (U_i - uref_i), bounds
-  for (int it = tid; it < (N + 1) * NX; it += 64) {
-    const int i = it / NX, k = it - i * NX;
-    const double q = i < N ? m.h * m.W[k] : m.We[k];
-    S[L.qv + i * VS + o2i(k)] = (TQ)(q * (D[L.X + it] - xref(i, k)));
+  TQ* gmu = st.mu + (size_t)b * 3 * nb;
+  if (gp) {
+    // alpha = Kx^-1 mu  (the OCP model evaluates k*(v_b) Kx^-1 p, src/gp/RGP.py:250-254)
+    for (int i = tid; i < 3 * nb; i += 64) {
+      const int d = i / nb, r = i % nb;
+      const TQ* kr = m.Kxinv + d * nb * nb + r * nb;
+      const TQ* mu = gmu + d * nb;
+      TQ t = 0;
+      int k = 0;
+      for (; k + 5 <= nb; k += 5) {
+        const TQ a0 = kr[k], a1 = kr[k + 1], a2 = kr[k + 2], a3 = kr[k + 3], a4 = kr[k + 4];
+        const TQ b0 = mu[k], b1 = mu[k + 1], b2 = mu[k + 2], b3 = mu[k + 3], b4 = mu[k + 4];
+        t += a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3 + a4 * b4;
+      }
+      for (; k < nb; ++k) t += kr[k] * mu[k];
+      S[L.alpha + i] = t;
+      S[L.basis + i] = m.basis[i];
+    }
+  }
+  if (tid < NX) D[L.x0 + tid] = st.x_meas[(size_t)b * NX + tid];
+  // X -> LDS and qv = Q_i (X_i - xref_i) in one pass over the record
+  constexpr int UNR = 5;
+  for (int base = 0; base < (N + 1) * NX; base += 64 * UNR) {
+    double xv[UNR], rv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int it = base + u * 64 + tid, itc = it < (N + 1) * NX ? it : 0, i = itc / NX;
+      xv[u] = gX[itc];
+      rv[u] = xref(i, itc - i * NX);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int it = base + u * 64 + tid;
+      if (it < (N + 1) * NX) {
+        const int i = it / NX, k = it - i * NX;
+        const double q = i < N ? m.h * m.W[k] : m.We[k];
+        D[L.X + it] = xv[u];
+        S[L.qv + i * VS + o2i(k)] = (TQ)(q * (xv[u] - rv[u]));
+      }
+    }
   }
   for (int it = tid; it < (N + 1) * 3; it += 64) S[L.qv + (it / 3) * VS + NX + it % 3] = 0;
   if (tid < VS) {   // weights in internal order: stage, terminal, input
@@ -1288,9 +1321,11 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
     S[L.wq + VS + tid] = tid < NX ? (TQ)m.We[i2o(tid)] : TQ(0);
     S[L.wq + 2 * VS + tid] = tid < NU ? (TQ)(m.h * m.W[NX + tid]) : TQ(0);
   }
+  // U -> LDS, r0 = R (U_i - uref_i), bounds
   for (int it = tid; it < nv; it += 64) {
     const int i = it >> 2, k = it & 3;
-    const double u = D[L.U + it];
+    const double u = gU[it];
+    D[L.U + it] = u;
     S[L.r0 + it] = (TQ)(m.h * m.W[NX + k] * (u - uref(i, k)));
     S[L.lb + it] = (TQ)(m.ulb[k] - u);
     S[L.ub + it] = (TQ)(m.uub[k] - u);
@@ -1299,17 +1334,6 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
     double* oy = st.yref + (size_t)b * N * NY;
     for (int it = tid; it < N * NY; it += 64) { const int i = it / NY, k = it - i * NY; oy[it] = k < NX ? xref(i, k) : m.uref[k - NX]; }
     if (tid < NX) st.yrefN[(size_t)b * NX + tid] = xref(N, tid);
-  }
-  TQ* gmu = st.mu + (size_t)b * 3 * nb;
-  if (gp) {
-    // alpha = Kx^-1 mu  (the OCP model evaluates k*(v_b) Kx^-1 p, src/gp/RGP.py:250-254)
-    for (int i = tid; i < 3 * nb; i += 64) {
-      const int d = i / nb, r = i % nb;
-      TQ t = 0;
-      for (int k = 0; k < nb; ++k) t += m.Kxinv[d * nb * nb + r * nb + k] * gmu[d * nb + k];
-      S[L.alpha + i] = t;
-      S[L.basis + i] = m.basis[i];
-    }
   }
   __syncthreads();
   PF_STOP(PF_LOAD);
@@ -1363,6 +1387,10 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   if (!(mode & MODE_POST)) return;
   // ---- 4. post: nominal prediction, cursor, drag estimate, RGP regress, statistics
   double* vbad = D + L.x0 + NX;   // [v_body(3), a_drag(3)]
+  if (gp) {   // stage the covariance while lane 0 integrates the nominal model (QP workspace is dead)
+    const TQ* gC = st.C + (size_t)b * 3 * nb * nb;
+    for (int i = tid; i < 3 * nb * nb; i += 64) S[L.rgp + i] = gC[i];
+  }
   if (tid == 0) {
     double x[NX], u[NU], xp[NX];
 #pragma unroll
@@ -1400,7 +1428,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
     gs[0] += ep; gs[1] += ev; gs[2] += 1; gs[3] = tmax(gs[3], ep);
   }
   __syncthreads();
-  if (gp) rgp_regress(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3);
+  if (gp) rgp_regress(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3, true);
 #ifdef MPCQ_PROFILE
   PF_STOP(PF_POST);
   pf.acc[PF_TOTAL] = __builtin_readcyclecounter() - t_begin;
