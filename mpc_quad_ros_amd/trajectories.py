@@ -98,3 +98,40 @@ def shard_range(total: int, rank: int, world: int):
     base, rem = divmod(total, world)
     lo = rank * base + min(rank, rem)
     return lo, base + (1 if rank < rem else 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Closed-form circle references of the reference's TrajectoryGenerator
+# (src/trajectory_generation/TrajectoryGenerator.py:41-130, loaded back through load_trajectory :223-244,
+# i.e. with the CSV's 6-decimal rounding, q = [1,0,0,0], rates 0).  kind: 'accelerating' (:41-78),
+# 'constant' (:82-103), 'acc_dec' (:105-131).
+def circle_trajectory(kind: str, radius: float, v_max: float, dt: float = 0.01, t_max: float = 10.0,
+                      start_point=(0.0, 0.0, 0.0)):
+    sp = np.asarray(start_point, dtype=float)
+    w_max = v_max / radius
+    if kind == "accelerating":
+        ts = np.arange(0, t_max, dt)
+        n = len(ts)
+        k = ((np.arange(n) + 1) / float(n) * 2) - 1
+        w = (np.sin((k * 2 * np.pi + np.pi * 3 / 2) * 0.5) + 1) / 2 * w_max
+        phi = np.cumsum(w * dt)
+    elif kind == "constant":
+        ts = np.arange(0, 2 * np.pi / w_max, dt)
+        w = np.full(len(ts), w_max)
+        phi = np.cumsum(w * dt)
+    elif kind == "acc_dec":
+        acc0 = w_max * w_max / 2.0 / np.pi
+        t_mid = w_max / acc0
+        ts = np.arange(0, 2 * t_mid, dt)
+        acc = np.where(ts < t_mid, acc0, -acc0)
+        w = np.cumsum(acc * dt)
+        phi = np.cumsum(w * dt)
+    else:
+        raise ValueError("kind must be 'accelerating', 'constant' or 'acc_dec'")
+    p = np.stack([radius * np.cos(phi) - radius, radius * np.sin(phi), np.zeros_like(phi)], axis=1) + sp
+    v = np.stack([-radius * w * np.sin(phi), radius * w * np.cos(phi), np.zeros_like(phi)], axis=1)
+    x = np.zeros((len(ts), NX))
+    x[:, 0:3] = np.round(p, 6)      # the reference writes '%.6f' CSV and reads it back
+    x[:, 3] = 1.0
+    x[:, 7:10] = np.round(v, 6)
+    return x, np.round(ts, 6)

@@ -174,7 +174,27 @@ def make_utils_vectors():
     print("wrote utils_vectors.npz", len(chunk_cases), "chunk cases")
 
 
+def make_circle_vectors():
+    """Outputs of the reference's closed-form circle generators (TrajectoryGenerator.py:41-131) read back through
+    its own load_trajectory (:223-244)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(REF, "src", "trajectory_generation"))
+    import TrajectoryGenerator as TG
+    g = TG.TrajectoryGenerator.__new__(TG.TrajectoryGenerator)
+    g.sampled_trajectory_filename = os.path.join(tempfile.mkdtemp(), "t.csv")
+    out = {}
+    g.sample_circle_trajectory_accelerating(10, 12, 30, 0.1, start_point=np.array([0.0, 0.0, 3.0]))
+    out["acc_x"], out["acc_t"] = g.load_trajectory()
+    g.sample_circle_trajectory(5.0, 8.0, 0.05, start_point=np.array([1.0, -2.0, 3.0]))
+    out["const_x"], out["const_t"] = g.load_trajectory()
+    g.sample_circle_trajectory_acc_dec(10, 10, 0.01)
+    out["ad_x"], out["ad_t"] = g.load_trajectory()
+    np.savez_compressed(os.path.join(OUT, "circle_vectors.npz"), **out)
+    print("wrote circle_vectors.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    make_circle_vectors()
     make_logs()
     make_rgp_vectors()
     make_utils_vectors()

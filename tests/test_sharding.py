@@ -97,3 +97,16 @@ def test_world_size_2_gloo_matches_single_rank():
     for r in res:
         assert np.allclose(r[5], red1, rtol=1e-12, atol=0)     # every rank holds the swarm statistic
     assert res[0][5][2] == total * K
+
+
+def test_circle_references_match_reference_generator():
+    """Closed-form circle trajectories (cheap half) against vectors produced by the reference's
+    TrajectoryGenerator (tests/golden/make_golden.py: make_circle_vectors)."""
+    from mpc_quad_ros_amd.trajectories import circle_trajectory
+    g = np.load(os.path.join(ROOT, "tests", "golden", "circle_vectors.npz"))
+    x, t = circle_trajectory("accelerating", 10, 12, dt=0.1, t_max=30, start_point=(0.0, 0.0, 3.0))
+    assert x.shape == g["acc_x"].shape and np.abs(x - g["acc_x"]).max() <= 1.5e-6 and np.abs(t - g["acc_t"]).max() < 1e-9
+    x, t = circle_trajectory("constant", 5.0, 8.0, dt=0.05, start_point=(1.0, -2.0, 3.0))
+    assert x.shape == g["const_x"].shape and np.abs(x - g["const_x"]).max() <= 1.5e-6
+    x, t = circle_trajectory("acc_dec", 10, 10, dt=0.01)
+    assert x.shape == g["ad_x"].shape and np.abs(x - g["ad_x"]).max() <= 1.5e-6
