@@ -208,7 +208,8 @@ struct EngineT : mpcq_engine {
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;
     m.h = c.T / c.N; m.dt_pred = c.dt_pred;
     m.mass = c.mass; m.tmax = c.max_thrust; m.g = c.g; m.aero_drag = c.aero_drag;
-    for (int i = 0; i < 3; ++i) { m.J[i] = c.J[i]; m.rotor_drag[i] = c.rotor_drag[i]; }
+    for (int i = 0; i < 3; ++i) { m.J[i] = c.J[i]; m.iJ[i] = 1.0 / c.J[i]; m.rotor_drag[i] = c.rotor_drag[i]; }
+    m.imass = 1.0 / c.mass;
     for (int i = 0; i < 4; ++i) {
       m.xf[i] = c.x_f[i]; m.yf[i] = c.y_f[i]; m.zl[i] = c.z_l_tau[i];
       m.ulb[i] = c.u_lb[i]; m.uub[i] = c.u_ub[i]; m.uref[i] = c.u_ref[i];

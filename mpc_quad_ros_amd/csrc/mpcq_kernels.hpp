@@ -58,6 +58,7 @@ struct DevModel {
   int N, nb, skip, Tmax, B, qp_max_iter, polish_max, warm_max;
   double h, dt_pred;
   double mass, J[3], tmax, xf[4], yf[4], zl[4], g;
+  double imass, iJ[3];   // reciprocals formed once on the host: no divisions in the model evaluations
   double W[NY], We[NX], ulb[NU], uub[NU], uref[NU];
   double rotor_drag[3], aero_drag;
   TQ qp_tol;    // final KKT tolerance (IPM-only fallback)
@@ -249,6 +250,13 @@ __device__ inline float  texp(float x)  { return __expf(x); }
 __device__ inline double texp(double x) { return exp(x); }
 __device__ inline float  trsqrt(float x)  { return rsqrtf(x); }
 __device__ inline double trsqrt(double x) { return 1.0 / sqrt(x); }
+// reciprocal of a positive, normal-range pivot: hardware estimate + Newton steps (no scaling / fix-up path)
+__device__ inline float  trcp(float x)  { return __fdividef(1.0f, x); }
+__device__ inline double trcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);   // v_rcp_f64 is good to ~2^-23: two steps reach the last ulp
+  return fma(fma(-x, r, 1.0), r, r);
+}
 __device__ inline float  tabs(float x)  { return fabsf(x); }
 __device__ inline double tabs(double x) { return fabs(x); }
 
@@ -261,11 +269,11 @@ template <typename T> __device__ inline void rotmat(const T* q, T* R) {
 
 // quad constants in the arithmetic type of the caller
 template <typename T> struct QC {
-  T mass, J[3], tmax, xf[4], yf[4], zl[4], g;
+  T mass, J[3], tmax, xf[4], yf[4], zl[4], g, imass, iJ[3];
   template <typename M> __device__ inline explicit QC(const M& m) {
-    mass = (T)m.mass; tmax = (T)m.tmax; g = (T)m.g;
+    mass = (T)m.mass; tmax = (T)m.tmax; g = (T)m.g; imass = (T)m.imass;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) J[i] = (T)m.J[i];
+    for (int i = 0; i < 3; ++i) { J[i] = (T)m.J[i]; iJ[i] = (T)m.iJ[i]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { xf[i] = (T)m.xf[i]; yf[i] = (T)m.yf[i]; zl[i] = (T)m.zl[i]; }
   }
@@ -286,14 +294,14 @@ __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const
   f[4] = T(0.5) * (r[0] * q[0] + r[2] * q[2] - r[1] * q[3]);
   f[5] = T(0.5) * (r[1] * q[0] - r[2] * q[1] + r[0] * q[3]);
   f[6] = T(0.5) * (r[2] * q[0] + r[1] * q[1] - r[0] * q[2]);
-  const T aT = m.tmax * (u[0] + u[1] + u[2] + u[3]) / m.mass;
+  const T aT = m.tmax * (u[0] + u[1] + u[2] + u[3]) * m.imass;
   f[7] = R[2] * aT; f[8] = R[5] * aT; f[9] = R[8] * aT - m.g;
   T ty = 0, tx = 0, tz = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { ty += u[j] * m.yf[j]; tx += u[j] * m.xf[j]; tz += u[j] * m.zl[j]; }
-  f[10] = (m.tmax * ty + (m.J[1] - m.J[2]) * r[1] * r[2]) / m.J[0];
-  f[11] = (-m.tmax * tx + (m.J[2] - m.J[0]) * r[2] * r[0]) / m.J[1];
-  f[12] = (m.tmax * tz + (m.J[0] - m.J[1]) * r[0] * r[1]) / m.J[2];
+  f[10] = (m.tmax * ty + (m.J[1] - m.J[2]) * r[1] * r[2]) * m.iJ[0];
+  f[11] = (-m.tmax * tx + (m.J[2] - m.J[0]) * r[2] * r[0]) * m.iJ[1];
+  f[12] = (m.tmax * tz + (m.J[0] - m.J[1]) * r[0] * r[1]) * m.iJ[2];
   T mg[3] = {0, 0, 0}, mp[3] = {0, 0, 0};
   const bool gp = alpha != nullptr;
   if (gp) {
@@ -399,14 +407,14 @@ __device__ inline void plant_eval(const M& m, const double* x, const double* u, 
   f[4] = 0.5 * (r[0] * q[0] + r[2] * q[2] - r[1] * q[3]);
   f[5] = 0.5 * (r[1] * q[0] - r[2] * q[1] + r[0] * q[3]);
   f[6] = 0.5 * (r[2] * q[0] + r[1] * q[1] - r[0] * q[2]);
-  const double aT = m.tmax * (u[0] + u[1] + u[2] + u[3]) / m.mass;
+  const double aT = m.tmax * (u[0] + u[1] + u[2] + u[3]) * m.imass;
   double vb[3], ad[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) vb[i] = R[i] * v[0] + R[3 + i] * v[1] + R[6 + i] * v[2];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const double sg = (double)((vb[i] > 0) - (vb[i] < 0));
-    ad[i] = -m.aero_drag * vb[i] * vb[i] * sg / m.mass - m.rotor_drag[i] * vb[i] / m.mass;
+    ad[i] = (-m.aero_drag * vb[i] * vb[i] * sg - m.rotor_drag[i] * vb[i]) * m.imass;
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) f[7 + i] = R[3 * i] * ad[0] + R[3 * i + 1] * ad[1] + R[3 * i + 2] * (ad[2] + aT);
@@ -414,9 +422,9 @@ __device__ inline void plant_eval(const M& m, const double* x, const double* u, 
   double ty = 0, tx = 0, tz = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { ty += u[j] * m.yf[j]; tx += u[j] * m.xf[j]; tz += u[j] * m.zl[j]; }
-  f[10] = (m.tmax * ty + (m.J[1] - m.J[2]) * r[1] * r[2]) / m.J[0];
-  f[11] = (-m.tmax * tx + (m.J[2] - m.J[0]) * r[2] * r[0]) / m.J[1];
-  f[12] = (m.tmax * tz + (m.J[0] - m.J[1]) * r[0] * r[1]) / m.J[2];
+  f[10] = (m.tmax * ty + (m.J[1] - m.J[2]) * r[1] * r[2]) * m.iJ[0];
+  f[11] = (-m.tmax * tx + (m.J[2] - m.J[0]) * r[2] * r[0]) * m.iJ[1];
+  f[12] = (m.tmax * tz + (m.J[0] - m.J[1]) * r[0] * r[1]) * m.iJ[2];
 }
 template <typename M>
 __device__ inline void plant_rk4(const M& m, double* x, const double* uin, double dt) {
@@ -487,8 +495,8 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, const Lds& L) {
   const TQ h = (TQ)m.h;
   const TQ a_s[4] = {TQ(0), TQ(0.5), TQ(0.5), TQ(1)};
   const TQ w_s[4] = {TQ(1), TQ(2), TQ(2), TQ(1)};
-  const TQ c10 = (qc.J[1] - qc.J[2]) / qc.J[0], c11 = (qc.J[2] - qc.J[0]) / qc.J[1], c12 = (qc.J[0] - qc.J[1]) / qc.J[2];
-  const TQ tm = qc.tmax / qc.mass;
+  const TQ c10 = (qc.J[1] - qc.J[2]) * qc.iJ[0], c11 = (qc.J[2] - qc.J[0]) * qc.iJ[1], c12 = (qc.J[0] - qc.J[1]) * qc.iJ[2];
+  const TQ tm = qc.tmax * qc.imass;
   for (int it = threadIdx.x; it < N * 14; it += 64) {
     const int i = it / 14, jp = it - i * 14, j = 3 + jp;
     const bool ucol = j >= NX;
@@ -498,7 +506,7 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, const Lds& L) {
     TQ jur[3] = {0, 0, 0};
 #pragma unroll
     for (int c = 0; c < NU; ++c)
-      if (j - NX == c) { jur[0] = qc.tmax * qc.yf[c] / qc.J[0]; jur[1] = -qc.tmax * qc.xf[c] / qc.J[1]; jur[2] = qc.tmax * qc.zl[c] / qc.J[2]; }
+      if (j - NX == c) { jur[0] = qc.tmax * qc.yf[c] * qc.iJ[0]; jur[1] = -qc.tmax * qc.xf[c] * qc.iJ[1]; jur[2] = qc.tmax * qc.zl[c] * qc.iJ[2]; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const TQ* sub = S + L.sub + i * SUBS + s * SUBW;
@@ -828,20 +836,23 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
 #pragma unroll
           for (int q = 0; q < a; ++q) Lm[a][q] *= mk[a] * mk[q];
       }
-      TQ id[4];
+      // LDL^T (no square roots; the reciprocal pivots are the only long-latency operations of the chain):
+      // Lm[a][q] (a > q) becomes the unit-lower factor, cm the unscaled column entries l*d
+      TQ id[4], cm[4][4];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
         TQ d = Lm[cc][cc];
 #pragma unroll
-        for (int k = 0; k < cc; ++k) d -= Lm[cc][k] * Lm[cc][k];
+        for (int k = 0; k < cc; ++k) d -= Lm[cc][k] * cm[cc][k];
         if (!(d > TQ(0))) ok = false;
         d = d > TQ(0) ? d : TQ(1);
-        id[cc] = trsqrt(d);
+        id[cc] = trcp(d);
 #pragma unroll
         for (int a = cc + 1; a < 4; ++a) {
           TQ s2 = Lm[a][cc];
 #pragma unroll
-          for (int k = 0; k < cc; ++k) s2 -= Lm[a][k] * Lm[cc][k];
+          for (int k = 0; k < cc; ++k) s2 -= Lm[a][k] * cm[cc][k];
+          cm[a][cc] = s2;
           Lm[a][cc] = s2 * id[cc];
         }
       }
@@ -854,18 +865,16 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
         g[j] = mk[j] * (S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j]);   // gt = rho + B^T p
       }
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-        TQ s2 = y[cc];
+      for (int cc = 1; cc < 4; ++cc) {
 #pragma unroll
-        for (int k = 0; k < cc; ++k) s2 -= Lm[cc][k] * y[k];
-        y[cc] = s2 * id[cc];
+        for (int k = 0; k < cc; ++k) y[cc] -= Lm[cc][k] * y[k];
       }
 #pragma unroll
-      for (int cc = 3; cc >= 0; --cc) {
-        TQ s2 = y[cc];
+      for (int cc = 0; cc < 4; ++cc) y[cc] *= id[cc];
 #pragma unroll
-        for (int k = cc + 1; k < 4; ++k) s2 -= Lm[k][cc] * y[k];
-        y[cc] = s2 * id[cc];
+      for (int cc = 2; cc >= 0; --cc) {
+#pragma unroll
+        for (int k = cc + 1; k < 4; ++k) y[cc] -= Lm[k][cc] * y[k];
       }
       // lanes < 13 store K[:,b] = -y and p_i[b] = (A^T p)[b] - y.gt ; lanes 13..16 store Lambda^-1[vj][:] = y and k_vj = -y.gt
       const TQ dot = y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3];

@@ -60,6 +60,7 @@ template <typename T> inline T __shfl_xor(T v, int mask) {
 inline float __expf(float x) { return std::exp(x); }
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 inline float __fdividef(float a, float b) { return a / b; }
+inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 inline int __double2loint(double d) { uint64_t u; std::memcpy(&u, &d, 8); return (int)(uint32_t)u; }
