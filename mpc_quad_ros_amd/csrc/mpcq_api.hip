@@ -137,6 +137,7 @@ struct EngineT : mpcq_engine {
   mpcq::DevState<T> st;
   mpcq::Lds L;
   size_t lds_bytes = 0;
+  void (*kstep)(const mpcq::DevModel<T>, const mpcq::DevState<T>, const int) = nullptr;
   std::vector<double> hbufd;
   T *d_basis = nullptr, *d_Kxinv = nullptr, *d_Kx = nullptr;
   double *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr, *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
@@ -145,7 +146,7 @@ struct EngineT : mpcq_engine {
   std::vector<double> Kx;
 
   ~EngineT() override {
-    void* ptrs[] = {st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
+    void* ptrs[] = {st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
                     st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -271,10 +272,25 @@ struct EngineT : mpcq_engine {
     if ((rc = dalloc(st.prof, Bz * mpcq::PF_N))) return rc;
 #endif
     st.tlen = d_tlen; st.traj = nullptr; st.x_meas = d_xin;
-    L = mpcq::lds_layout(N, nb);
-    lds_bytes = mpcq::lds_bytes<T>(L);
-    if (lds_bytes > 160 * 1024) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS (N/nb too large for this precision)");
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::step_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // Placement of the per-stage records (AB'', c, qv): LDS when the whole batch is resident at once that way,
+    // otherwise global memory (L2 / MALL) if that lets more instances share a CU.  MPCQ_STAGE_MEM=lds|global overrides.
+    int n_cu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+    const size_t lds_cu = 160 * 1024;
+    const mpcq::Lds Ll = mpcq::lds_layout(N, nb, 0), Lg = mpcq::lds_layout(N, nb, 1);
+    const size_t bl = mpcq::lds_bytes<T>(Ll), bg = mpcq::lds_bytes<T>(Lg);
+    const size_t occ_l = bl <= lds_cu ? lds_cu / bl : 0, occ_g = bg <= lds_cu ? lds_cu / bg : 0;
+    bool gab = occ_l == 0 || (occ_g > occ_l && (size_t)B > occ_l * n_cu);
+    if (const char* t = getenv("MPCQ_STAGE_MEM")) gab = t[0] == 'g' || t[0] == 'G';
+    if (gab && occ_g == 0) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS (N/nb too large for this precision)");
+    if (!gab && occ_l == 0) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS with MPCQ_STAGE_MEM=lds");
+    m.gab = gab ? 1 : 0;
+    if (getenv("MPCQ_VERBOSE")) fprintf(stderr, "mpcq: stage records in %s, LDS %zu B per instance (%zu per CU), lds-only layout %zu B (%zu per CU)\n", gab ? "global memory" : "LDS", gab ? bg : bl, gab ? occ_g : occ_l, bl, occ_l);
+    L = gab ? Lg : Ll;
+    lds_bytes = gab ? bg : bl;
+    if (gab && (rc = dalloc(st.stage, Bz * L.gtotal))) return rc;
+    kstep = gab ? &mpcq::step_kernel<T, true> : &mpcq::step_kernel<T, false>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::regress_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     return reset();
   }
@@ -326,7 +342,7 @@ struct EngineT : mpcq_engine {
 
   int launch_step(int mode) {
     HIP_TRY(hipEventRecord(ev0, stream));
-    hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(64), lds_bytes, stream, m, st, mode);
+    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, st, mode);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
@@ -403,7 +419,7 @@ struct EngineT : mpcq_engine {
     s2.x_meas = (const double*)d_x;
     if (d_w) s2.w = (double*)d_w;
     HIP_TRY(hipEventRecord(ev0, stream));
-    hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
@@ -418,7 +434,7 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipEventRecord(ev0, stream));
     for (int k = 0; k < K; ++k) {
       HIP_TRY(hipEventRecord(kev[2 * k], stream));
-      hipLaunchKernelGGL(mpcq::step_kernel<T>, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+      hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
       HIP_TRY(hipEventRecord(kev[2 * k + 1], stream));
       hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, sim_dt, B);
     }

@@ -56,6 +56,7 @@ __device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __
 template <typename TQ>
 struct DevModel {
   int N, nb, skip, Tmax, B, qp_max_iter, polish_max, warm_max;
+  int gab;   // stage records (AB'', c, qv) live in DevState::stage instead of LDS (must match the kernel instantiation)
   double h, dt_pred;
   double mass, J[3], tmax, xf[4], yf[4], zl[4], g;
   double imass, iJ[3];   // reciprocals formed once on the host: no divisions in the model evaluations
@@ -89,6 +90,7 @@ struct DevState {
   const int* tlen;
   int* status;
   int* qp_iter;
+  TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
   unsigned long long* prof;   // [B][PF_N] (diagnostic build only)
 };
 
@@ -101,21 +103,35 @@ struct Lds {
   int AB, c, qv, r0, lb, ub, alpha, basis, wq;
   int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv, spv;
   int sub, rgp, qtotal;
+  int gab, zb, gx, gtotal;   // stage data (AB'', c, qv) in global memory? ; LDS zero block ; GP exchange scratch ; global elements per instance
 };
 __host__ __device__ inline int al4(int v) { return (v + 3) & ~3; }
-__host__ __device__ inline Lds lds_layout(int N, int nb) {
+__host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   Lds L;
-  int o = 0;
+  int o = 0, g = 0;
   auto take = [&](int n) { int r = o; o += al4(n); return r; };
+  auto gtake = [&](int n) { int r = g; g += al4(n); return r; };
   L.X = take((N + 1) * NX);
   L.U = take(N * NU);
   L.x0 = take(NX + 8);   // + [v_body(3), a_drag(3)] scratch of the post phase
   L.dbytes = o * 8;
   o = 0;
   const int nv = N * NU;
-  L.AB = take(N * ABS + VS);   // + one zero block read by padding lanes
-  L.c = take(N * VS);
-  L.qv = take((N + 1) * VS);
+  L.gab = gab;
+  if (gab) {   // per-stage data streamed from global memory (L2 / MALL): LDS keeps only the QP workspace
+    L.AB = gtake(N * ABS + VS);   // + one zero block read by padding lanes
+    L.c = gtake(N * VS);
+    L.qv = gtake((N + 1) * VS);
+    L.zb = take(VS);
+    L.gx = take(22 * 8);   // 21 lane triples + the idle lane 63
+  } else {
+    L.AB = take(N * ABS + VS);
+    L.c = take(N * VS);
+    L.qv = take((N + 1) * VS);
+    L.zb = L.AB + N * ABS;
+    L.gx = L.AB;   // exchange scratch of shoot_states: AB'' is not written before shoot_sens
+  }
+  L.gtotal = (g + 15) & ~15;
   L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv);
   L.alpha = take(3 * nb);
   L.basis = take(3 * nb);
@@ -218,8 +234,9 @@ __device__ inline void vl_store(double* base, int h, const double (&v)[4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) base[h + 4 * s] = v[s];
 }
-// Operand addressing that is valid on every lane (padding lanes read the zero block behind AB'' with
-// stride 0), so operand loads are unconditional and can be issued a stage ahead.
+// Operand addressing that is valid on every lane (padding lanes read a zero block with stride 0), so
+// operand loads are unconditional and can be issued ahead of their stage.  `P` below is the base the
+// offsets refer to: the LDS workspace S, or the per-instance global stage record A (GAB layouts).
 // k-major operand: lane (h,c) <- AB''[RI(s,h)][c]
 template <typename TQ> struct KMaj {
   int off[4], str[4];
@@ -231,21 +248,31 @@ template <typename TQ> struct KMaj {
       str[s] = k < NX ? ABS : 0;
     }
   }
-  __device__ inline void load(const TQ* S, int i, TQ (&o)[4]) const {
+  __device__ inline void load(const TQ* P, int i, TQ (&o)[4]) const {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) o[s] = S[off[s] + i * str[s]];
+    for (int s = 0; s < 4; ++s) o[s] = P[off[s] + i * str[s]];
   }
 };
-// row-major operand: lane (h,c) <- M[c][RI(s,h)] for a row-major matrix of `rows` rows at `base` (stage stride `sst`)
+// row-major operand: lane (h,c) <- M[c][RI(s,h)] for a row-major matrix of `rows` rows at `base` (stage stride
+// `sst`); lanes c >= rows read the zero block at `zero`
 template <typename TQ> struct RMaj {
   int off, str, hh;
-  __device__ inline RMaj(const Lds& L, int N, int base, int sst, int rows, int h, int c) {
-    off = c < rows ? base + c * ABW : L.AB + N * ABS;
+  __device__ inline RMaj(int zero, int base, int sst, int rows, int h, int c) {
+    off = c < rows ? base + c * ABW : zero;
     str = c < rows ? sst : 0;
     hh = h;
   }
-  __device__ inline void load(const TQ* S, int i, TQ (&o)[4]) const { vl_load(S + off + i * str, hh, o); }
+  __device__ inline void load(const TQ* P, int i, TQ (&o)[4]) const { vl_load(P + off + i * str, hh, o); }
 };
+// Operands are fetched PD stages ahead of their use: one stage hides the LDS latency, the global stage
+// records need more.  q[0] is the current stage; shift() retires it.
+template <bool GAB> struct Depth { static constexpr int PD = GAB ? 2 : 1; };
+template <typename TQ, int PD> __device__ inline void shift(TQ (&q)[PD + 1][4]) {
+#pragma unroll
+  for (int d = 0; d < PD; ++d)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) q[d][s] = q[d + 1][s];
+}
 __device__ inline float  texp(float x)  { return __expf(x); }
 __device__ inline double texp(double x) { return exp(x); }
 __device__ inline float  trsqrt(float x)  { return rsqrtf(x); }
@@ -448,14 +475,14 @@ __device__ inline void plant_rk4(const M& m, double* x, const double* uin, doubl
 // ------------------------------------------------------------------ shooting
 // pass 1: lane (triple) per interval, 4 RK substages in TQ; writes records + gap c_i = Phi_i - X_{i+1}
 // (the part X_i - X_{i+1} of the gap is formed in double)
-template <typename TQ>
-__device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, const Lds& L, bool gp) {
+template <typename TQ, bool GAB>
+__device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* A, const Lds& L, bool gp) {
   const int N = m.N, lane = threadIdx.x;
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
   // with the GP in the model the three axis sums (nb exps each) of a stage go to three neighbouring lanes
   const int per = gp ? 3 : 1, lanes_used = gp ? 63 : 64, spr = lanes_used / per;   // stages per round
-  TQ* gx = S + L.AB + (lane / 3) * 8;   // exchange scratch: AB'' is not written before shoot_sens
+  TQ* gx = S + L.gx + (lane / 3) * 8;   // LDS exchange scratch
   for (int base = 0; base < N; base += spr) {
     const int il = lane / per, d = lane - il * per;
     const bool valid = lane < lanes_used && base + il < N;
@@ -482,14 +509,14 @@ __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* 
 #pragma unroll
       for (int j = 0; j < NX; ++j) {
         const double gap = (D[L.X + i * NX + j] - D[L.X + (i + 1) * NX + j]) + (double)(h / 6 * (acc[j] + k[j]));
-        S[L.c + i * VS + o2i(j)] = (TQ)gap;
+        A[L.c + i * VS + o2i(j)] = (TQ)gap;
       }
     }
   }
 }
 // pass 2: item = (interval i, column j of [A|B], j = 3..16) -> AB'[i][r][j-3]
-template <typename TQ>
-__device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, const Lds& L) {
+template <typename TQ, bool GAB>
+__device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
   const int N = m.N;
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
@@ -536,13 +563,13 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, const Lds& L) {
 #pragma unroll
       for (int r = 0; r < NX; ++r) { acc[r] += w_s[s] * Sn[r]; Sp[r] = Sn[r]; }
     }
-    TQ* AB = S + L.AB + i * ABS;
+    TQ* AB = A + L.AB + i * ABS;
 #pragma unroll
     for (int r = 0; r < NX; ++r) AB[o2i(r) * ABW + jp] = ((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r];
   }
   // zero the two pad columns (read by the vectorised 4-wide loads)
-  for (int it = threadIdx.x; it < N * NX * 2; it += 64) S[L.AB + (it >> 1) * ABW + 14 + (it & 1)] = 0;
-  for (int it = threadIdx.x; it < N * 3; it += 64) S[L.c + (it / 3) * VS + NX + it % 3] = 0;
+  for (int it = threadIdx.x; it < N * NX * 2; it += 64) A[L.AB + (it >> 1) * ABW + 14 + (it & 1)] = 0;
+  for (int it = threadIdx.x; it < N * 3; it += 64) A[L.c + (it / 3) * VS + NX + it % 3] = 0;
 }
 
 // ------------------------------------------------------------------ QP: vector sweeps
@@ -572,96 +599,111 @@ template <typename TQ> __device__ constexpr int in_s(int j) { return sizeof(TQ) 
 __host__ __device__ inline int GI(int i) { return (i >> 2) * VS + 10 + (i & 3); }   // input i of the nv-vector inside a 16-stride array
 
 // forward rollout dx_{i+1} = A dx_i + B z_i (+ c_i); dx_0 taken from S[dxo + 0..15]
-template <typename TQ>
-__device__ inline void rollout(const DevModel<TQ>& m, TQ* S, const Lds& L, int dxo, int zo, bool with_c) {
+template <typename TQ, bool GAB>
+__device__ inline void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dxo, int zo, bool with_c) {
   const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
   const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[zo + i];
   __syncthreads();
   const Sel<TQ> sel(h);
-  const RMaj<TQ> rm(L, N, L.AB, ABS, NX, h, c);
-  TQ vA[4], cur[4], nxt[4], zv[4], cv[4], zn[4], cn[4];
+  const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
+  constexpr int PD = Depth<GAB>::PD;
+  TQ vA[4], qa[PD + 1][4], qz[PD + 1][4], qc[PD + 1][4];
   vl_load(S + dxo, h, vA);
-  rm.load(S, 0, cur);
-  vl_load(S + L.vin, h, zv);
-  vl_load(S + L.c, h, cv);
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int id = d < N ? d : N - 1;
+    rm.load(A, id, qa[d]);
+    vl_load(S + L.vin + id * VS, h, qz[d]);
+    vl_load(A + L.c + id * VS, h, qc[d]);
+  }
   for (int i = 0; i < N; ++i) {
-    const int ip = i + 1 < N ? i + 1 : i;
-    rm.load(S, ip, nxt);
-    vl_load(S + L.vin + ip * VS, h, zn);
-    vl_load(S + L.c + ip * VS, h, cn);
+    const int ip = i + PD < N ? i + PD : N - 1;
+    rm.load(A, ip, qa[PD]);
+    vl_load(S + L.vin + ip * VS, h, qz[PD]);
+    vl_load(A + L.c + ip * VS, h, qc[PD]);
     TQ vB[4], acc[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      vB[s] = sel.A[s] * vA[s] + sel.U[s] * zv[s];
-      acc[s] = (with_c ? cv[s] : TQ(0)) + sel.P[s] * vA[s];
+      vB[s] = sel.A[s] * vA[s] + sel.U[s] * qz[0][s];
+      acc[s] = (with_c ? qc[0][s] : TQ(0)) + sel.P[s] * vA[s];
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, cur[s], vB[s]);
+    for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], vB[s]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; cur[s] = nxt[s]; zv[s] = zn[s]; cv[s] = cn[s]; }
+    for (int s = 0; s < 4; ++s) vA[s] = acc[s];
+    shift<TQ, PD>(qa); shift<TQ, PD>(qz); shift<TQ, PD>(qc);
     if (vl) vl_store(S + dxo + (i + 1) * VS, h, vA);
   }
   __syncthreads();
 }
 
 // adjoint sweep: grad = d/dz of the QP objective at (dx(z), z)
-template <typename TQ>
-__device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, const Lds& L) {
+template <typename TQ, bool GAB>
+__device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
   const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
   const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
   __syncthreads();
   const Sel<TQ> sel(h);
   const KMaj<TQ> km(L, N, h, c);
-  TQ qd[4], qe[4], pi[4], dxv[4], qvv[4], cur[4], nxt[4];
+  constexpr int PD = Depth<GAB>::PD;
+  TQ qd[4], qe[4], pi[4], dxv[4], qvv[4], qa[PD + 1][4], qq[PD + 1][4];
   vl_load(S + L.wq, h, qd);
   vl_load(S + L.wq + VS, h, qe);
   vl_load(S + L.dx + N * VS, h, dxv);
-  vl_load(S + L.qv + N * VS, h, qvv);
+  vl_load(A + L.qv + N * VS, h, qvv);
 #pragma unroll
   for (int s = 0; s < 4; ++s) pi[s] = qe[s] * dxv[s] + qvv[s];
-  km.load(S, N - 1, cur);
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int id = N - 1 - d > 0 ? N - 1 - d : 0;
+    km.load(A, id, qa[d]);
+    vl_load(A + L.qv + id * VS, h, qq[d]);
+  }
   for (int i = N - 1; i >= 0; --i) {
-    km.load(S, i > 0 ? i - 1 : 0, nxt);
+    const int ip = i - PD > 0 ? i - PD : 0;
+    km.load(A, ip, qa[PD]);
+    vl_load(A + L.qv + ip * VS, h, qq[PD]);
     TQ gv[4], acc[4] = {0, 0, 0, 0};
     vl_load(S + L.dx + i * VS, h, dxv);
-    vl_load(S + L.qv + i * VS, h, qvv);
     vl_load(S + L.vin + i * VS, h, gv);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, cur[s], pi[s]);
+    for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], pi[s]);
     TQ g[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       g[s] = acc[s] + gv[s];
-      pi[s] = sel.A[s] * acc[s] + sel.P[s] * pi[s] + (qd[s] * dxv[s] + qvv[s]);
-      cur[s] = nxt[s];
+      pi[s] = sel.A[s] * acc[s] + sel.P[s] * pi[s] + (qd[s] * dxv[s] + qq[0][s]);
     }
+    shift<TQ, PD>(qa); shift<TQ, PD>(qq);
     if (vl) vl_store(S + L.grad + i * VS, h, g);
   }
   __syncthreads();
 }
 
 // backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
-template <typename TQ>
-__device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, const Lds& L, bool polish) {
+template <typename TQ, bool GAB>
+__device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, bool polish) {
   const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
   const Sel<TQ> sel(h);
   const KMaj<TQ> km(L, N, h, c);
   const int lj = lane < NU ? lane : 0;
-  TQ pv[4] = {0, 0, 0, 0}, cur[4], nxt[4];
-  km.load(S, N - 1, cur);
+  constexpr int PD = Depth<GAB>::PD;
+  TQ pv[4] = {0, 0, 0, 0}, qa[PD + 1][4];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) km.load(A, N - 1 - d > 0 ? N - 1 - d : 0, qa[d]);
   for (int i = N - 1; i >= 0; --i) {
-    km.load(S, i > 0 ? i - 1 : 0, nxt);
+    km.load(A, i - PD > 0 ? i - PD : 0, qa[PD]);
     TQ rv[4], acc[4] = {0, 0, 0, 0};
     vl_load(S + L.vin + i * VS, h, rv);
     const TQ kk = S[L.K + i * KS + h * ABW + c];
     const V4<TQ> li = *reinterpret_cast<const V4<TQ>*>(S + L.Linv + i * 16 + lj * 4);
     const TQ rtj = S[L.rt + i * NU + lj];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, cur[s], pv[s]);
+    for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], pv[s]);
     // gt_j = rho_j + (B^T p)_j sits in slot 10+j of column 14; fetch the four of them as scalars
     TQ g[4];
 #pragma unroll
@@ -672,7 +714,8 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, const 
     for (int s = 0; s < 4; ++s) acc[s] = sel.A[s] * acc[s] + sel.P[s] * pv[s];
     mfma(acc, kk, gh);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { pv[s] = acc[s]; cur[s] = nxt[s]; }
+    for (int s = 0; s < 4; ++s) pv[s] = acc[s];
+    shift<TQ, PD>(qa);
     if (lane < NU) {
       const TQ kvj = -(li.a * g[0] + li.b * g[1] + li.c * g[2] + li.d * g[3]);
       S[L.vin + i * VS + lane] = (polish && rtj < TQ(0)) ? TQ(0) : kvj;
@@ -682,20 +725,22 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, const 
 }
 
 // forward sweep: Dx_0 = 0; dz_i = K_i Dx_i + k_i ; Dx_{i+1} = A Dx_i + B dz_i   (out: S[dzo], S[L.Dx])
-template <typename TQ>
-__device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& L, int dzo) {
+template <typename TQ, bool GAB>
+__device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo) {
   const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   const Sel<TQ> sel(h);
-  const RMaj<TQ> rm(L, N, L.AB, ABS, NX, h, c), rk(L, N, L.K, KS, NU, h, c);
-  TQ vA[4] = {0, 0, 0, 0}, ac[4], an[4], kc[4], kn[4], kv[4], kvn[4];
+  const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c), rk(L.zb, L.K, KS, NU, h, c);
+  constexpr int PD = Depth<GAB>::PD;
+  TQ vA[4] = {0, 0, 0, 0}, qa[PD + 1][4], kc[4], kn[4], kv[4], kvn[4];
   if (lane < VS) S[L.Dx + lane] = 0;
-  rm.load(S, 0, ac);
+#pragma unroll
+  for (int d = 0; d < PD; ++d) rm.load(A, d < N ? d : N - 1, qa[d]);
   rk.load(S, 0, kc);
   vl_load(S + L.vin, h, kv);
   for (int i = 0; i < N; ++i) {
     const int ip = i + 1 < N ? i + 1 : i;
-    rm.load(S, ip, an);
+    rm.load(A, i + PD < N ? i + PD : N - 1, qa[PD]);
     rk.load(S, ip, kn);
     vl_load(S + L.vin + ip * VS, h, kvn);
     TQ acc[4];
@@ -714,9 +759,10 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& 
     for (int j = 0; j < 4; ++j)
       if (h == in_h<TQ>(j)) vB[in_s<TQ>(j)] = d[j];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, ac[s], vB[s]);
+    for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], vB[s]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; ac[s] = an[s]; kc[s] = kn[s]; kv[s] = kvn[s]; }
+    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; kc[s] = kn[s]; kv[s] = kvn[s]; }
+    shift<TQ, PD>(qa);
     if (vl) vl_store(S + L.Dx + (i + 1) * VS, h, vA);
   }
   __syncthreads();
@@ -731,8 +777,8 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, const Lds& 
 //   P_i  = Q + G + M^T K           with G = [A|B]^T P [A|B] restricted to states, assembled from F'', T1'', P.
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
-template <typename TQ, bool polish>
-__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L) {
+template <typename TQ, bool GAB, bool polish>
+__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
   const int N = m.N, lane = threadIdx.x, nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
@@ -773,11 +819,11 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
   const int o4str = lane < NX ? ABW : 1;
   const TQ o4sgn = lane < NX ? TQ(-1) : TQ(1), tbm = lane < NX ? TQ(1) : TQ(0);
   TQ cur[4], nxt[4];
-  km.load(S, N - 1, cur);
+  km.load(A, N - 1, cur);
   if (lane < VS) S[L.spv + lane] = 0;
   __syncthreads();
   for (int i = N - 1; i >= 0; --i) {
-    km.load(S, i > 0 ? i - 1 : 0, nxt);
+    km.load(A, i > 0 ? i - 1 : 0, nxt);   // a factorisation stage is long enough to hide one global fetch
     TQ acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc1, Pop[s], cur[s]);              // T1''
@@ -917,8 +963,8 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, const Lds& L
 // Mehrotra predictor-corrector iterations; every Newton system is one Riccati factorisation + two
 // vector sweeps.  Continues from the current (z, sl, su, ll, lu, dx, grad) until |r_d| <= tol*gm and
 // mu <= tol.  returns 0 converged / 1 NaN / 2 iteration cap / 4 stage Hessian not positive definite
-template <typename TQ>
-__device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
+template <typename TQ, bool GAB>
+__device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
   int status = 2;
   const int maxit = m.qp_max_iter;
@@ -936,10 +982,10 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    const bool fok = riccati_factor<TQ, false>(m, S, L);
+    const bool fok = riccati_factor<TQ, GAB, false>(m, S, A, L);
     PF_STOP(PF_FACTOR);
     if (!fok) { status = 4; break; }
-    PF_START(); riccati_forward(m, S, L, L.dza); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<TQ, GAB>(m, S, A, L, L.dza); PF_STOP(PF_FWD);
     TQ aff = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
@@ -969,8 +1015,8 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       S[L.rho + i] = rd - tdiv(rcl, sl) + tdiv(rcu, su);
     }
     __syncthreads();
-    PF_START(); riccati_backward_vec(m, S, L, false); PF_STOP(PF_BWD);
-    PF_START(); riccati_forward(m, S, L, L.dz); PF_STOP(PF_FWD);
+    PF_START(); riccati_backward_vec<TQ, GAB>(m, S, A, L, false); PF_STOP(PF_BWD);
+    PF_START(); riccati_forward<TQ, GAB>(m, S, A, L, L.dz); PF_STOP(PF_FWD);
     TQ ap = 1, ad = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
@@ -999,7 +1045,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     }
     for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
     __syncthreads();
-    PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+    PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
   }
   return status;
 }
@@ -1009,8 +1055,8 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
 // the wrong sign are released (the worst one, only at a minimiser of the current working set), inputs
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
-template <typename TQ>
-__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+template <typename TQ, bool GAB>
+__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
   bool fresh = warm;   // warm start: z = 0 pins nothing new (pinned inputs have bound 0), caller's dx / grad are current
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
@@ -1036,7 +1082,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
       __syncthreads();
       if (sizeof(TQ) == 8 && nact == 0) { settled = true; break; }   // no multipliers to check, step exact to f64 rounding
-      PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+      PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
     } else {
       for (int i = tid; i < nv; i += 64) {
         const TQ a = S[L.act + i];
@@ -1045,8 +1091,8 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
       }
       __syncthreads();
       if (!fresh) {
-        PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-        PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+        PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+        PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
       }
     }
     fresh = false;
@@ -1087,10 +1133,10 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    if (refactor) { const bool fok = riccati_factor<TQ, true>(m, S, L); PF_STOP(PF_FACTOR); if (!fok) return false; }
-    else { riccati_backward_vec(m, S, L, true); PF_STOP(PF_BWD); }
+    if (refactor) { const bool fok = riccati_factor<TQ, GAB, true>(m, S, A, L); PF_STOP(PF_FACTOR); if (!fok) return false; }
+    else { riccati_backward_vec<TQ, GAB>(m, S, A, L, true); PF_STOP(PF_BWD); }
     refactor = false;
-    PF_START(); riccati_forward(m, S, L, L.dz); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<TQ, GAB>(m, S, A, L, L.dz); PF_STOP(PF_FWD);
     TQ alpha = 1;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
@@ -1122,7 +1168,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
     __syncthreads();
   }
   if (settled && sizeof(TQ) == 4) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
-    PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
   }
   return settled;
 }
@@ -1135,19 +1181,19 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, const Lds& L, const 
 // either, IPM iterations down to the final tolerance.  The QP is strictly convex, so every branch ends on
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
-template <typename TQ>
-__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* status, const bool try_warm PF_ARG) {
+template <typename TQ, bool GAB>
+__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int* status, const bool try_warm PF_ARG) {
   const int N = m.N, nv = N * NU, tid = threadIdx.x;
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
   if (try_warm && m.warm_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.z + i] = 0;
     __syncthreads();
-    PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-    PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+    PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
     for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
     gm = wave_max(gm);
-    if (polish(m, S, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // settles right after a rollout of the final z
+    if (polish<TQ, GAB>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // settles right after a rollout of the final z
       *status = 0;
       return wpasses;
     }
@@ -1160,28 +1206,28 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, const Lds& L, int* 
     S[L.z + i] = z0; S[L.sl + i] = z0 - lb; S[L.su + i] = ub - z0;
   }
   __syncthreads();
-  PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-  PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
+  PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+  PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
   gm = 1;
   for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
   gm = wave_max(gm);
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = TQ(0.1) * gm / S[L.sl + i]; S[L.lu + i] = TQ(0.1) * gm / S[L.su + i]; }
   __syncthreads();
-  int st = ipm_run(m, S, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+  int st = ipm_run<TQ, GAB>(m, S, A, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
   bool need_roll = true;
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
-    if (polish(m, S, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
+    if (polish<TQ, GAB>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
-      PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-      PF_START(); adjoint(m, S, L); PF_STOP(PF_ADJ);
-      st = ipm_run(m, S, L, m.qp_tol, gm, it PF_PASS);
+      PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+      PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
+      st = ipm_run<TQ, GAB>(m, S, A, L, m.qp_tol, gm, it PF_PASS);
     }
   }
-  if (need_roll) { PF_START(); rollout(m, S, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
+  if (need_roll) { PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
   *status = st;
   return it + passes + wpasses;
 }
@@ -1247,14 +1293,16 @@ __device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, T
 // reference row (get_reference_chunk, src/utils/utils.py:897-931) for horizon node j
 __device__ inline long chunk_row(int j, int have, int idx, int skip, int len) { return j < have ? (long)idx + (long)j * skip : (long)len - 1; }
 
-template <typename TQ>
+template <typename TQ, bool GAB>
 __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const DevState<TQ> st, const int mode) {
   extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = m.N, nb = m.nb, nv = N * NU;
-  const Lds L = lds_layout(N, nb);
+  const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
   double* D = reinterpret_cast<double*>(smem_raw);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
+  TQ* A = S;   // base of the stage records
+  if (GAB) A = st.stage + (size_t)b * L.gtotal;
   const bool gp = nb > 0;
 #ifdef MPCQ_PROFILE
   Prof pf;
@@ -1320,11 +1368,11 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
         const int i = it / NX, k = it - i * NX;
         const double q = i < N ? m.h * m.W[k] : m.We[k];
         D[L.X + it] = xv[u];
-        S[L.qv + i * VS + o2i(k)] = (TQ)(q * (xv[u] - rv[u]));
+        A[L.qv + i * VS + o2i(k)] = (TQ)(q * (xv[u] - rv[u]));
       }
     }
   }
-  for (int it = tid; it < (N + 1) * 3; it += 64) S[L.qv + (it / 3) * VS + NX + it % 3] = 0;
+  for (int it = tid; it < (N + 1) * 3; it += 64) A[L.qv + (it / 3) * VS + NX + it % 3] = 0;
   if (tid < VS) {   // weights in internal order: stage, terminal, input
     S[L.wq + tid] = tid < NX ? (TQ)(m.h * m.W[i2o(tid)]) : TQ(0);
     S[L.wq + VS + tid] = tid < NX ? (TQ)m.We[i2o(tid)] : TQ(0);
@@ -1347,20 +1395,20 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   __syncthreads();
   PF_STOP(PF_LOAD);
   // ---- 1. shooting
-  shoot_states(m, D, S, L, gp);
+  shoot_states<TQ, GAB>(m, D, S, A, L, gp);
   __syncthreads();
   PF_STOP(PF_SHOOT_X);
-  shoot_sens(m, S, L);
+  shoot_sens<TQ, GAB>(m, S, A, L);
   __syncthreads();
   PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
-  if (tid < VS) { S[L.dx + tid] = 0; S[L.AB + N * ABS + tid] = 0; }
+  if (tid < VS) { S[L.dx + tid] = 0; A[L.AB + N * ABS + tid] = 0; S[L.zb + tid] = 0; }
   for (int it = tid; it < N * VS; it += 64) S[L.vin + it] = 0;
   __syncthreads();
   if (tid < NX) S[L.dx + o2i(tid)] = (TQ)(D[L.x0 + tid] - D[L.X + tid]);   // dx_0 = x_meas - X_0 (lbx = ubx = x_init)
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  const int iters = solve_qp(m, S, L, &status, st.qp_iter[b] > 0 PF_PASS);
+  const int iters = solve_qp<TQ, GAB>(m, S, A, L, &status, st.qp_iter[b] > 0 PF_PASS);
   // ---- 3. full step (iterate accumulated in double)
   for (int it = tid; it < (N + 1) * NX; it += 64) {
     const int i = it / NX, k = it - i * NX;
@@ -1464,7 +1512,7 @@ __global__ void predict_kernel(const DevModel<TQ> m, const double* x, const doub
 template <typename TQ>
 __global__ void regress_kernel(const DevModel<TQ> m, const DevState<TQ> st, const double* vb, const double* ad) {
   extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
-  const Lds L = lds_layout(m.N, m.nb);
+  const Lds L = lds_layout(m.N, m.nb, m.gab);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
   const int b = blockIdx.x;
   rgp_regress(m, S, L, st.mu + (size_t)b * 3 * m.nb, st.C + (size_t)b * 3 * m.nb * m.nb, vb + (size_t)b * 3, ad + (size_t)b * 3);

@@ -149,6 +149,8 @@ constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 const char* hipGetErrorString(hipError_t);
 hipError_t hipGetDeviceCount(int*);
 hipError_t hipSetDevice(int);
+struct hipDeviceProp_t { int multiProcessorCount; };
+hipError_t hipGetDeviceProperties(hipDeviceProp_t*, int);
 hipError_t hipMalloc(void**, size_t);
 hipError_t hipFree(void*);
 hipError_t hipMemset(void*, int, size_t);
