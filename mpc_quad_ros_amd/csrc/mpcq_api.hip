@@ -289,7 +289,10 @@ struct EngineT : mpcq_engine {
     L = gab ? Lg : Ll;
     lds_bytes = gab ? bg : bl;
     if (gab && (rc = dalloc(st.stage, Bz * L.gtotal))) return rc;
-    kstep = gab ? &mpcq::step_kernel<T, true> : &mpcq::step_kernel<T, false>;
+    kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false>>;
+    // shape-specialised instances (compile-time N and nb): BASELINE configs[1]
+    if (N == 20 && nb == 10 && !getenv("MPCQ_GENERIC"))
+      kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true, 20, 10>> : &mpcq::step_kernel<mpcq::Cfg<T, false, 20, 10>>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::regress_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     return reset();

@@ -44,8 +44,13 @@ __device__ inline void pf_start(Prof& p) { p.t = __builtin_readcyclecounter(); }
 __device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __builtin_readcyclecounter(); p.acc[k] += n - p.t; p.t = n; }
 #define PF_ARG , Prof& pf
 #define PF_PASS , pf
+#ifdef MPCQ_PROFILE_NOSTAMP
+#define PF_START()
+#define PF_STOP(k)
+#else
 #define PF_START() pf_start(pf)
 #define PF_STOP(k) pf_stop(pf, k)
+#endif
 #else
 #define PF_ARG
 #define PF_PASS
@@ -472,12 +477,24 @@ __device__ inline void plant_rk4(const M& m, double* x, const double* uin, doubl
   for (int i = 0; i < NX; ++i) x[i] = x[i] + dt / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
 }
 
+// ------------------------------------------------------------------ kernel configurations
+// One step-kernel instantiation per Cfg.  N = 0 / NB = -1 read the horizon and the RGP basis size from the
+// model at run time (any shape); fixed values turn every LDS offset, trip count and index division into a
+// compile-time constant for the shapes that matter (see mpcq_api.hip for the table of instances).
+template <typename T_, bool GAB_, int N_ = 0, int NB_ = -1> struct Cfg {
+  using T = T_;
+  static constexpr bool GAB = GAB_;
+  static constexpr int N = N_, NB = NB_;
+};
+template <typename C, typename M> __device__ inline int cN(const M& m) { return C::N > 0 ? C::N : m.N; }
+template <typename C, typename M> __device__ inline int cNB(const M& m) { return C::NB >= 0 ? C::NB : m.nb; }
+
 // ------------------------------------------------------------------ shooting
 // pass 1: lane (triple) per interval, 4 RK substages in TQ; writes records + gap c_i = Phi_i - X_{i+1}
 // (the part X_i - X_{i+1} of the gap is formed in double)
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* A, const Lds& L, bool gp) {
-  const int N = m.N, lane = threadIdx.x;
+  const int N = cN<C>(m), lane = threadIdx.x;
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
   // with the GP in the model the three axis sums (nb exps each) of a stage go to three neighbouring lanes
@@ -495,16 +512,16 @@ __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* 
     for (int j = 0; j < NU; ++j) u[j] = (TQ)D[L.U + i * NU + j];
     const TQ* al = gp ? S + L.alpha : nullptr;
     TQ* sub = (valid && d == 0) ? S + L.sub + i * SUBS : nullptr;
-    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, x, u, al, S + L.basis, k, sub, gd, gx);
+    model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, x, u, al, S + L.basis, k, sub, gd, gx);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = x[j] + h / 2 * k[j]; }
-    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + SUBW : nullptr, gd, gx);
+    model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + SUBW : nullptr, gd, gx);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] += 2 * k[j]; xt[j] = x[j] + h / 2 * k[j]; }
-    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + 2 * SUBW : nullptr, gd, gx);
+    model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + 2 * SUBW : nullptr, gd, gx);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] += 2 * k[j]; xt[j] = x[j] + h * k[j]; }
-    model_eval<TQ, TQ>(qc, m.nb, m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + 3 * SUBW : nullptr, gd, gx);
+    model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + 3 * SUBW : nullptr, gd, gx);
     if (valid && d == 0) {
 #pragma unroll
       for (int j = 0; j < NX; ++j) {
@@ -515,9 +532,9 @@ __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* 
   }
 }
 // pass 2: item = (interval i, column j of [A|B], j = 3..16) -> AB'[i][r][j-3]
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
-  const int N = m.N;
+  const int N = cN<C>(m);
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
   const TQ a_s[4] = {TQ(0), TQ(0.5), TQ(0.5), TQ(1)};
@@ -599,9 +616,9 @@ template <typename TQ> __device__ constexpr int in_s(int j) { return sizeof(TQ) 
 __host__ __device__ inline int GI(int i) { return (i >> 2) * VS + 10 + (i & 3); }   // input i of the nv-vector inside a 16-stride array
 
 // forward rollout dx_{i+1} = A dx_i + B z_i (+ c_i); dx_0 taken from S[dxo + 0..15]
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dxo, int zo, bool with_c) {
-  const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
   const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[zo + i];
   __syncthreads();
@@ -639,9 +656,9 @@ __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 }
 
 // adjoint sweep: grad = d/dz of the QP objective at (dx(z), z)
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
-  const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
   const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
   __syncthreads();
@@ -683,9 +700,9 @@ __device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 }
 
 // backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, bool polish) {
-  const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
   const Sel<TQ> sel(h);
@@ -725,9 +742,9 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A,
 }
 
 // forward sweep: Dx_0 = 0; dz_i = K_i Dx_i + k_i ; Dx_{i+1} = A Dx_i + B dz_i   (out: S[dzo], S[L.Dx])
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo) {
-  const int N = m.N, lane = threadIdx.x, h = lane >> 4, c = lane & 15;
+  const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   const Sel<TQ> sel(h);
   const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c), rk(L.zb, L.K, KS, NU, h, c);
@@ -777,9 +794,9 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
 //   P_i  = Q + G + M^T K           with G = [A|B]^T P [A|B] restricted to states, assembled from F'', T1'', P.
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
-template <typename TQ, bool GAB, bool polish>
+template <typename C, bool polish, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
-  const int N = m.N, lane = threadIdx.x, nv = N * NU, h = lane >> 4, c = lane & 15;
+  const int N = cN<C>(m), lane = threadIdx.x, nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
   // stage input Hessian diagonals R~ (negative value = input pinned by the polish)
@@ -963,9 +980,9 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
 // Mehrotra predictor-corrector iterations; every Newton system is one Riccati factorisation + two
 // vector sweeps.  Continues from the current (z, sl, su, ll, lu, dx, grad) until |r_d| <= tol*gm and
 // mu <= tol.  returns 0 converged / 1 NaN / 2 iteration cap / 4 stage Hessian not positive definite
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
-  const int N = m.N, nv = N * NU, tid = threadIdx.x;
+  const int N = cN<C>(m), nv = N * NU, tid = threadIdx.x;
   int status = 2;
   const int maxit = m.qp_max_iter;
   for (; it < maxit; ++it) {
@@ -982,10 +999,10 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    const bool fok = riccati_factor<TQ, GAB, false>(m, S, A, L);
+    const bool fok = riccati_factor<C, false>(m, S, A, L);
     PF_STOP(PF_FACTOR);
     if (!fok) { status = 4; break; }
-    PF_START(); riccati_forward<TQ, GAB>(m, S, A, L, L.dza); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C>(m, S, A, L, L.dza); PF_STOP(PF_FWD);
     TQ aff = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
@@ -1015,8 +1032,8 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
       S[L.rho + i] = rd - tdiv(rcl, sl) + tdiv(rcu, su);
     }
     __syncthreads();
-    PF_START(); riccati_backward_vec<TQ, GAB>(m, S, A, L, false); PF_STOP(PF_BWD);
-    PF_START(); riccati_forward<TQ, GAB>(m, S, A, L, L.dz); PF_STOP(PF_FWD);
+    PF_START(); riccati_backward_vec<C>(m, S, A, L, false); PF_STOP(PF_BWD);
+    PF_START(); riccati_forward<C>(m, S, A, L, L.dz); PF_STOP(PF_FWD);
     TQ ap = 1, ad = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
@@ -1045,7 +1062,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
     }
     for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
     __syncthreads();
-    PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
+    PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
   }
   return status;
 }
@@ -1055,10 +1072,10 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
 // the wrong sign are released (the worst one, only at a minimiser of the current working set), inputs
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
   bool fresh = warm;   // warm start: z = 0 pins nothing new (pinned inputs have bound 0), caller's dx / grad are current
-  const int N = m.N, nv = N * NU, tid = threadIdx.x;
+  const int N = cN<C>(m), nv = N * NU, tid = threadIdx.x;
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
     for (int i = tid; i < nv; i += 64) {
       S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
@@ -1082,7 +1099,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
       for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
       __syncthreads();
       if (sizeof(TQ) == 8 && nact == 0) { settled = true; break; }   // no multipliers to check, step exact to f64 rounding
-      PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
+      PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
     } else {
       for (int i = tid; i < nv; i += 64) {
         const TQ a = S[L.act + i];
@@ -1091,8 +1108,8 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
       }
       __syncthreads();
       if (!fresh) {
-        PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-        PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
+        PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+        PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
       }
     }
     fresh = false;
@@ -1133,10 +1150,10 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    if (refactor) { const bool fok = riccati_factor<TQ, GAB, true>(m, S, A, L); PF_STOP(PF_FACTOR); if (!fok) return false; }
-    else { riccati_backward_vec<TQ, GAB>(m, S, A, L, true); PF_STOP(PF_BWD); }
+    if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, L); PF_STOP(PF_FACTOR); if (!fok) return false; }
+    else { riccati_backward_vec<C>(m, S, A, L, true); PF_STOP(PF_BWD); }
     refactor = false;
-    PF_START(); riccati_forward<TQ, GAB>(m, S, A, L, L.dz); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C>(m, S, A, L, L.dz); PF_STOP(PF_FWD);
     TQ alpha = 1;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
@@ -1168,7 +1185,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
     __syncthreads();
   }
   if (settled && sizeof(TQ) == 4) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
-    PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
   }
   return settled;
 }
@@ -1181,19 +1198,19 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
 // either, IPM iterations down to the final tolerance.  The QP is strictly convex, so every branch ends on
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
-template <typename TQ, bool GAB>
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int* status, const bool try_warm PF_ARG) {
-  const int N = m.N, nv = N * NU, tid = threadIdx.x;
+  const int N = cN<C>(m), nv = N * NU, tid = threadIdx.x;
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
   if (try_warm && m.warm_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.z + i] = 0;
     __syncthreads();
-    PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-    PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
+    PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
     for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
     gm = wave_max(gm);
-    if (polish<TQ, GAB>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // settles right after a rollout of the final z
+    if (polish<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // settles right after a rollout of the final z
       *status = 0;
       return wpasses;
     }
@@ -1206,28 +1223,28 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
     S[L.z + i] = z0; S[L.sl + i] = z0 - lb; S[L.su + i] = ub - z0;
   }
   __syncthreads();
-  PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-  PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
+  PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+  PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
   gm = 1;
   for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
   gm = wave_max(gm);
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = TQ(0.1) * gm / S[L.sl + i]; S[L.lu + i] = TQ(0.1) * gm / S[L.su + i]; }
   __syncthreads();
-  int st = ipm_run<TQ, GAB>(m, S, A, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+  int st = ipm_run<C>(m, S, A, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
   bool need_roll = true;
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
-    if (polish<TQ, GAB>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
+    if (polish<C>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
-      PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-      PF_START(); adjoint<TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
-      st = ipm_run<TQ, GAB>(m, S, A, L, m.qp_tol, gm, it PF_PASS);
+      PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+      PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
+      st = ipm_run<C>(m, S, A, L, m.qp_tol, gm, it PF_PASS);
     }
   }
-  if (need_roll) { PF_START(); rollout<TQ, GAB>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
+  if (need_roll) { PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
   *status = st;
   return it + passes + wpasses;
 }
@@ -1236,18 +1253,18 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 // RGP.regress / RGP.predict of the reference (src/gp/RGP.py:199-208,303-330), scalar new point:
 //   J = k* Kx^-1 ; mu_p = J mu ; Cp = sf2 - J k* + J C J^T ; G = C J^T/(Cp + sn2) ;
 //   mu += G (y - mu_p) ; C -= G (J C)      (not symmetrised, as in the reference)
-template <typename TQ>
+template <typename C, typename TQ = typename C::T>
 __device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu, TQ* gC, const double* vb, const double* ad, bool c_staged = false) {
-  const int n = m.nb, tid = threadIdx.x, NT = blockDim.x, n3 = 3 * n, nn = n * n;
-  TQ* C = S + L.rgp;
-  TQ* ks = C + al4(3 * nn);
+  const int n = cNB<C>(m), tid = threadIdx.x, NT = blockDim.x, n3 = 3 * n, nn = n * n;
+  TQ* Cw = S + L.rgp;
+  TQ* ks = Cw + al4(3 * nn);
   TQ* Jt = ks + al4(n3);
   TQ* JC = Jt + al4(n3);
   TQ* CJ = JC + al4(n3);
   TQ* mu = CJ + al4(n3);
   TQ* sc = mu + al4(n3);
   if (!c_staged)
-    for (int i = tid; i < 3 * nn; i += NT) C[i] = gC[i];
+    for (int i = tid; i < 3 * nn; i += NT) Cw[i] = gC[i];
   for (int i = tid; i < n3; i += NT) {
     const int d = i / n;
     const TQ dl = (TQ)vb[d] - m.basis[i];
@@ -1265,7 +1282,7 @@ __device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, T
   for (int i = tid; i < n3; i += NT) {
     const int d = i / n, j = i % n;
     TQ t = 0, s = 0;
-    for (int k = 0; k < n; ++k) { t += Jt[d * n + k] * C[d * nn + k * n + j]; s += C[d * nn + j * n + k] * Jt[d * n + k]; }
+    for (int k = 0; k < n; ++k) { t += Jt[d * n + k] * Cw[d * nn + k * n + j]; s += Cw[d * nn + j * n + k] * Jt[d * n + k]; }
     JC[i] = t;
     CJ[i] = s;
   }
@@ -1285,7 +1302,7 @@ __device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, T
   }
   for (int i = tid; i < 3 * nn; i += NT) {
     const int d = i / nn, r = (i / n) % n, c = i % n;
-    gC[i] = C[i] - CJ[d * n + r] * sc[d * 4 + 1] * JC[d * n + c];
+    gC[i] = Cw[i] - CJ[d * n + r] * sc[d * 4 + 1] * JC[d * n + c];
   }
 }
 
@@ -1293,11 +1310,11 @@ __device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, T
 // reference row (get_reference_chunk, src/utils/utils.py:897-931) for horizon node j
 __device__ inline long chunk_row(int j, int have, int idx, int skip, int len) { return j < have ? (long)idx + (long)j * skip : (long)len - 1; }
 
-template <typename TQ, bool GAB>
-__global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const DevState<TQ> st, const int mode) {
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
+__global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
   extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int N = m.N, nb = m.nb, nv = N * NU;
+  const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
   const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
   double* D = reinterpret_cast<double*>(smem_raw);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
@@ -1395,10 +1412,10 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   __syncthreads();
   PF_STOP(PF_LOAD);
   // ---- 1. shooting
-  shoot_states<TQ, GAB>(m, D, S, A, L, gp);
+  shoot_states<C>(m, D, S, A, L, gp);
   __syncthreads();
   PF_STOP(PF_SHOOT_X);
-  shoot_sens<TQ, GAB>(m, S, A, L);
+  shoot_sens<C>(m, S, A, L);
   __syncthreads();
   PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
   if (tid < VS) { S[L.dx + tid] = 0; A[L.AB + N * ABS + tid] = 0; S[L.zb + tid] = 0; }
@@ -1408,7 +1425,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  const int iters = solve_qp<TQ, GAB>(m, S, A, L, &status, st.qp_iter[b] > 0 PF_PASS);
+  const int iters = solve_qp<C>(m, S, A, L, &status, st.qp_iter[b] > 0 PF_PASS);
   // ---- 3. full step (iterate accumulated in double)
   for (int it = tid; it < (N + 1) * NX; it += 64) {
     const int i = it / NX, k = it - i * NX;
@@ -1485,7 +1502,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<TQ> m, const De
     gs[0] += ep; gs[1] += ev; gs[2] += 1; gs[3] = tmax(gs[3], ep);
   }
   __syncthreads();
-  if (gp) rgp_regress(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3, true);
+  if (gp) rgp_regress<C>(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3, true);
 #ifdef MPCQ_PROFILE
   PF_STOP(PF_POST);
   pf.acc[PF_TOTAL] = __builtin_readcyclecounter() - t_begin;
@@ -1515,7 +1532,7 @@ __global__ void regress_kernel(const DevModel<TQ> m, const DevState<TQ> st, cons
   const Lds L = lds_layout(m.N, m.nb, m.gab);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
   const int b = blockIdx.x;
-  rgp_regress(m, S, L, st.mu + (size_t)b * 3 * m.nb, st.C + (size_t)b * 3 * m.nb * m.nb, vb + (size_t)b * 3, ad + (size_t)b * 3);
+  rgp_regress<Cfg<TQ, false>>(m, S, L, st.mu + (size_t)b * 3 * m.nb, st.C + (size_t)b * 3 * m.nb * m.nb, vb + (size_t)b * 3, ad + (size_t)b * 3);
 }
 
 // closed-loop plant: n_sub RK4 substeps of the drag plant from the engine's plant state with input w

@@ -63,10 +63,53 @@ def test_swarm_closed_loop_config2_shape():
 
 
 def test_long_horizon_config5_shape():
-    # fp64 working set at N=50/nb=50 exceeds the 160 KiB LDS of a CU in the current layout: config 5 runs in f32
+    # N=50 / nb=50 in f32: the whole working set fits the LDS of a CU
     worst = pc.case_swarm_closed_loop(make, B=4, N=50, nb=50, K=6, precision=1)
     print("config-5 shape, f32: worst relative control deviation", worst)
     assert worst < 1e-4
+
+
+def test_long_horizon_config5_shape_f64():
+    # in fp64 the stage records (AB'', gaps, cost gradients) of N=50 do not fit LDS next to the QP workspace:
+    # the engine places them in global memory by itself
+    worst = pc.case_swarm_closed_loop(make, B=4, N=50, nb=50, K=6)
+    print("config-5 shape, f64: worst relative control deviation", worst)
+    assert worst < 1e-6
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_kernel_variants_agree(precision, monkeypatch):
+    """The four step-kernel variants of one precision (stage records in LDS / global memory, shape-specialised /
+    generic instantiation) are the same algorithm: identical working sets, controls equal to rounding."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N, nb, K = 64, 20, 10, 25
+    traj, lens = swarm_trajectories(11, 0, B)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    out = {}
+    for mem in ("lds", "global"):
+        for generic in (False, True):
+            monkeypatch.setenv("MPCQ_STAGE_MEM", mem)
+            if generic:
+                monkeypatch.setenv("MPCQ_GENERIC", "1")
+            else:
+                monkeypatch.delenv("MPCQ_GENERIC", raising=False)
+            e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision))
+            e.set_trajectories(traj, lens)
+            e.sim_reset(x0)
+            ws = []
+            for k in range(K):
+                e.sim_steps(1, 2, 5e-3)
+                assert (e.get_status() == 0).all()
+                ws.append(e.sim_get_state()[1].copy())
+            out[(mem, generic)] = np.array(ws)
+    ref = out[("lds", True)]
+    tol = 1e-9 if precision == 0 else 2e-4
+    for k, v in out.items():
+        assert pc.rel_err(v, ref) < tol, (k, pc.rel_err(v, ref))
+    if precision == 0:   # same arithmetic, two instantiations: agreement far below the solver tolerances
+        assert pc.rel_err(out[("lds", True)], out[("global", True)]) < 1e-12
+        assert pc.rel_err(out[("lds", False)], out[("global", False)]) < 1e-12
 
 
 @pytest.mark.parametrize("name,K", [("log_traj1_v10_a10_gp0.npz", 60), ("log_traj0_v10_a10_gp2.npz", 60)])
