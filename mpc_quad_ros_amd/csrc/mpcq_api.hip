@@ -14,6 +14,14 @@
 #include "../../include/mpcq.h"
 #include "mpcq_kernels.hpp"
 
+namespace mpcq {   // mpcq_spec.hip
+template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
+StepFn<double> spec_step_f64(int N, int nb, bool gab);
+StepFn<float> spec_step_f32(int N, int nb, bool gab);
+}
+static mpcq::StepFn<double> spec_step(int N, int nb, bool gab, double*) { return mpcq::spec_step_f64(N, nb, gab); }
+static mpcq::StepFn<float> spec_step(int N, int nb, bool gab, float*) { return mpcq::spec_step_f32(N, nb, gab); }
+
 namespace {
 
 thread_local std::string g_err;
@@ -290,9 +298,9 @@ struct EngineT : mpcq_engine {
     lds_bytes = gab ? bg : bl;
     if (gab && (rc = dalloc(st.stage, Bz * L.gtotal))) return rc;
     kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false>>;
-    // shape-specialised instances (compile-time N and nb): BASELINE configs[1]
-    if (N == 20 && nb == 10 && !getenv("MPCQ_GENERIC"))
-      kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true, 20, 10>> : &mpcq::step_kernel<mpcq::Cfg<T, false, 20, 10>>;
+    // shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
+    if (!getenv("MPCQ_GENERIC"))
+      if (auto k = spec_step(N, nb, gab, (T*)nullptr)) kstep = k;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::regress_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     return reset();

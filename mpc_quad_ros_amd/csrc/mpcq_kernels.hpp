@@ -57,6 +57,11 @@ __device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __
 #define PF_START()
 #define PF_STOP(k)
 #endif
+#if defined(MPCQ_PROFILE) && defined(MPCQ_PROFILE_FWD)
+#define PF_FINE(k) pf_stop(pf, k)
+#else
+#define PF_FINE(k)
+#endif
 
 template <typename TQ>
 struct DevModel {
@@ -98,6 +103,8 @@ struct DevState {
   TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
   unsigned long long* prof;   // [B][PF_N] (diagnostic build only)
 };
+
+extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base), shared by the kernels and their out-of-line phases
 
 // ------------------------------------------------------------------ LDS layout
 // doubles first (offsets in doubles from the LDS base), then the TQ region (offsets in TQ elements
@@ -185,6 +192,14 @@ template <int CTRL> __device__ inline float dpp(float v) { return __int_as_float
 template <int CTRL> __device__ inline double dpp(double v) {
   return __hiloint2double(dpp<CTRL>(__double2hiint(v)), dpp<CTRL>(__double2loint(v)));
 }
+// value held by lane ^ 32 (rows 0,1 <-> rows 2,3): one v_permlane32_swap per dword, no LDS, no SGPR round trip
+__device__ inline int xrow2(int v) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const u2 r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+}
+__device__ inline float xrow2(float v) { return __int_as_float(xrow2(__float_as_int(v))); }
+__device__ inline double xrow2(double v) { return __hiloint2double(xrow2(__double2hiint(v)), xrow2(__double2loint(v))); }
 // wave-wide reductions: butterfly inside each row of 16 with DPP, then the 4 row results through SGPRs
 template <typename T, typename OP> __device__ inline T wave_reduce(T v, OP op) {
   v = op(v, dpp<0xB1>(v));    // quad_perm [1,0,3,2]
@@ -220,6 +235,9 @@ __device__ inline void mfma(double (&acc)[4], double a, double b) {
   typedef double d4 __attribute__((ext_vector_type(4)));
   d4 cc = {acc[0], acc[1], acc[2], acc[3]};
   cc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cc, 0, 0, 0);
+#ifdef MPCQ_DGEMM_SETTLE
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(cc));
+#endif
   acc[0] = cc[0]; acc[1] = cc[1]; acc[2] = cc[2]; acc[3] = cc[3];
 }
 // A state-sized vector rides in column 14 of a tile: lane (h, 14) holds slots RI(s,h), s = 0..3.
@@ -245,12 +263,14 @@ __device__ inline void vl_store(double* base, int h, const double (&v)[4]) {
 // k-major operand: lane (h,c) <- AB''[RI(s,h)][c]
 template <typename TQ> struct KMaj {
   int off[4], str[4];
-  __device__ inline KMaj(const Lds& L, int N, int h, int c) {
+  // with_gap: pad column 14 of the operand carries the gap c_i (so that P c comes out of the product P AB'' for free)
+  __device__ inline KMaj(const Lds& L, int N, int h, int c, bool with_gap = false) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int k = RI<TQ>(s, h);
       off[s] = k < NX ? L.AB + k * ABW + c : L.AB + N * ABS + c;
       str[s] = k < NX ? ABS : 0;
+      if (with_gap && c == 14 && k < NX) { off[s] = L.c + k; str[s] = VS; }
     }
   }
   __device__ inline void load(const TQ* P, int i, TQ (&o)[4]) const {
@@ -742,45 +762,73 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A,
 }
 
 // forward sweep: Dx_0 = 0; dz_i = K_i Dx_i + k_i ; Dx_{i+1} = A Dx_i + B dz_i   (out: S[dzo], S[L.Dx])
-template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo) {
+// affine: the sweep of the affine recursion instead: starts from dx_0 in S[L.dx], adds the gaps c_i and writes the
+// state trajectory to S[L.dx] (z_i = K_i dx_i + k_i to S[dzo])
+template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
+__device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
   const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   const Sel<TQ> sel(h);
   const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c), rk(L.zb, L.K, KS, NU, h, c);
   constexpr int PD = Depth<GAB>::PD;
-  TQ vA[4] = {0, 0, 0, 0}, qa[PD + 1][4], kc[4], kn[4], kv[4], kvn[4];
-  if (lane < VS) S[L.Dx + lane] = 0;
+  const int xo = affine ? L.dx : L.Dx;
+  TQ vA[4] = {0, 0, 0, 0}, qa[PD + 1][4], qc[PD + 1][4], kc[4], kn[4], kv[4], kvn[4];
+  if (affine) vl_load(S + L.dx, h, vA);
+  else if (lane < VS) S[L.Dx + lane] = 0;
 #pragma unroll
-  for (int d = 0; d < PD; ++d) rm.load(A, d < N ? d : N - 1, qa[d]);
+  for (int d = 0; d < PD; ++d) {
+    rm.load(A, d < N ? d : N - 1, qa[d]);
+    if (affine) vl_load(A + L.c + (d < N ? d : N - 1) * VS, h, qc[d]);
+  }
   rk.load(S, 0, kc);
   vl_load(S + L.vin, h, kv);
   for (int i = 0; i < N; ++i) {
-    const int ip = i + 1 < N ? i + 1 : i;
-    rm.load(A, i + PD < N ? i + PD : N - 1, qa[PD]);
+    const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1;
+    rm.load(A, ig, qa[PD]);
+    if (affine) vl_load(A + L.c + ig * VS, h, qc[PD]);
     rk.load(S, ip, kn);
     vl_load(S + L.vin + ip * VS, h, kvn);
+    PF_FINE(11);
     TQ acc[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[s] = sel.K[s] * kv[s];
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc, kc[s], vA[s]);     // dz = K Dx + k : slots 0..3 of column 14
-    TQ d[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) d[j] = sizeof(TQ) == 4 ? bc(acc[j], 14) : bc(acc[0], 16 * j + 14);   // slot j = RI(s,h)
-    if (lane < NU) S[dzo + i * NU + lane] = lane == 0 ? d[0] : (lane == 1 ? d[1] : (lane == 2 ? d[2] : d[3]));
+    PF_FINE(12);
     TQ vB[4];
+#ifdef MPCQ_NO_XROW
+    if (false) {
+#else
+    if (sizeof(TQ) == 8) {
+#endif
+      // f64: dz_j sits in register 0 of lane (j, 14) and is needed in slot 10 + j = RI(s, h) of the same column:
+      // (h, s) = (2,2), (3,2), (0,3), (1,3), i.e. two rows away -> one cross-half swap, no broadcast through SGPRs
+      const TQ dz = acc[0], t = xrow2(dz);
+      if (vl) S[dzo + i * NU + h] = dz;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { vB[s] = sel.A[s] * vA[s]; acc[s] = sel.P[s] * vA[s]; }
+      for (int s = 0; s < 4; ++s) { vB[s] = sel.A[s] * vA[s]; acc[s] = sel.P[s] * vA[s] + (affine ? qc[0][s] : TQ(0)); }
+      vB[2] = h >= 2 ? t : vB[2];
+      vB[3] = h < 2 ? t : vB[3];
+    } else {
+      TQ d[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (h == in_h<TQ>(j)) vB[in_s<TQ>(j)] = d[j];
+      for (int j = 0; j < 4; ++j) d[j] = sizeof(TQ) == 4 ? bc(acc[j], 14) : bc(acc[0], 16 * j + 14);   // slot j = RI(s,h)
+      if (lane < NU) S[dzo + i * NU + lane] = lane == 0 ? d[0] : (lane == 1 ? d[1] : (lane == 2 ? d[2] : d[3]));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { vB[s] = sel.A[s] * vA[s]; acc[s] = sel.P[s] * vA[s] + (affine ? qc[0][s] : TQ(0)); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (h == in_h<TQ>(j)) vB[in_s<TQ>(j)] = d[j];
+    }
+    PF_FINE(13);
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], vB[s]);
+    PF_FINE(14);
 #pragma unroll
     for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; kc[s] = kn[s]; kv[s] = kvn[s]; }
     shift<TQ, PD>(qa);
-    if (vl) vl_store(S + L.Dx + (i + 1) * VS, h, vA);
+    if (affine) shift<TQ, PD>(qc);
+    if (vl) vl_store(S + xo + (i + 1) * VS, h, vA);
   }
   __syncthreads();
 }
@@ -794,8 +842,8 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
 //   P_i  = Q + G + M^T K           with G = [A|B]^T P [A|B] restricted to states, assembled from F'', T1'', P.
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
-template <typename C, bool polish, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
+template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
+__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr) {
   const int N = cN<C>(m), lane = threadIdx.x, nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
@@ -809,9 +857,10 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
   }
   for (int it = lane; it < N * NU * 3; it += 64) S[L.K + (it / 3) * ABW + NX + it % 3] = 0;   // K pad columns
   const Sel<TQ> sel(h);
-  const KMaj<TQ> km(L, N, h, c);
+  const KMaj<TQ> km(L, N, h, c, affine);
   // P_N = W_e as an accumulator tile: Pop[s] = P[RI(s,h)][c]; per-lane masks for the assembly of Q + G
-  TQ Pop[4], pv[4] = {0, 0, 0, 0}, qdg[4], mA2[4], mA1[4], mPo[4], mT[4];
+  TQ Pop[4], pv[4] = {0, 0, 0, 0}, qdg[4], mA2[4], mA1[4], mPo[4], mT[4], gmax = 0;
+  if (affine) vl_load(A + L.qv + N * VS, h, pv);   // p_N = q_N
   int toff[4];
   const bool cq = c < 10, cp = c >= 10 && c < NX;
 #pragma unroll
@@ -841,12 +890,15 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
   __syncthreads();
   for (int i = N - 1; i >= 0; --i) {
     km.load(A, i > 0 ? i - 1 : 0, nxt);   // a factorisation stage is long enough to hide one global fetch
+    TQ qvi = 0;
+    if (affine) qvi = A[L.qv + i * VS + b3];   // consumed at the end of the stage
     TQ acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc1, Pop[s], cur[s]);              // T1''
-    TQ b2[4];
+    // column 14 of T1'' is P c_i (zero without the gap column): the vector pushed through AB''^T is p + P c
+    TQ b2[4], vs[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b2[s] = vl ? pv[s] : acc1[s];
+    for (int s = 0; s < 4; ++s) { vs[s] = affine ? pv[s] + acc1[s] : pv[s]; b2[s] = vl ? vs[s] : acc1[s]; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc2, cur[s], b2[s]);               // F'' ; column 14 = AB''^T p
     // hand rows 10..13 over to the stage-Hessian lanes through LDS
@@ -869,7 +921,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
     if (vl) {
       TQ idp[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) idp[s] = sel.P[s] * pv[s];   // identity columns: (A^T p)[p] = p[p]
+      for (int s = 0; s < 4; ++s) idp[s] = sel.P[s] * vs[s];   // identity columns: (A^T v)[p] = v[p]
       vl_store(S + L.stv, h, idp);
       vl_store(S + L.stv + VS, h, acc2);                         // rows 0..9: A^T p ; rows 10..13: B^T p
     }
@@ -926,6 +978,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
         const TQ mv = S[m3off + j * m3str];
         y[j] = mk[j] * (lane < NX ? mv : ((lane - NX) == j ? TQ(1) : TQ(0)));
         g[j] = mk[j] * (S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j]);   // gt = rho + B^T p
+        if (affine) gmax = tmax(gmax, tabs(g[j]));
       }
 #pragma unroll
       for (int cc = 1; cc < 4; ++cc) {
@@ -947,6 +1000,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
 #pragma unroll
         for (int j = 0; j < 4; ++j) o4[j * o4str] = o4sgn * y[j] * (polish ? mk[j] : TQ(1));
         TQ ex = tbm * tb - dot;
+        if (affine && lane < NX) ex += qvi;   // stage gradient q_i enters the recursion directly
         if (polish && lane >= NX) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -973,6 +1027,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
     __syncthreads();
   }
   __syncthreads();
+  if (affine && gscale) *gscale = gmax;   // every lane saw every stage gradient
   return wave_min<int>(ok ? 1 : 0) != 0;   // all lanes agree on definiteness
 }
 
@@ -1002,7 +1057,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
     const bool fok = riccati_factor<C, false>(m, S, A, L);
     PF_STOP(PF_FACTOR);
     if (!fok) { status = 4; break; }
-    PF_START(); riccati_forward<C>(m, S, A, L, L.dza); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C>(m, S, A, L, L.dza PF_PASS); PF_STOP(PF_FWD);
     TQ aff = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
@@ -1033,7 +1088,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
     }
     __syncthreads();
     PF_START(); riccati_backward_vec<C>(m, S, A, L, false); PF_STOP(PF_BWD);
-    PF_START(); riccati_forward<C>(m, S, A, L, L.dz); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
     TQ ap = 1, ad = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
@@ -1073,8 +1128,8 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
-  bool fresh = warm;   // warm start: z = 0 pins nothing new (pinned inputs have bound 0), caller's dx / grad are current
+__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+  bool fresh = false;
   const int N = cN<C>(m), nv = N * NU, tid = threadIdx.x;
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
     for (int i = tid; i < nv; i += 64) {
@@ -1086,21 +1141,46 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
       S[L.act + i] = S[L.ll + i] > S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > S[L.su + i] ? TQ(1) : TQ(0));
   }
   __syncthreads();
-  const TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
-  const TQ tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
+  TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
+  TQ tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
   bool refactor = true, settled = false, full = false;
   int nact = 1;   // pinned inputs in the working set (unknown before the first count)
   bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
+  bool dx_done = false;   // the forward sweep already produced the state trajectory (affine pass)
   TQ gF_prev = TQ(1e30);
   for (passes = 0; passes < max_passes; ++passes) {
-    if (full) {
-      // the last pass took a full Newton step with an unchanged working set: the state trajectory is affine in z
-      for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
+    const bool aff = warm && passes == 0;
+    if (aff) {
+      // Warm start from z = 0 with every pinned input at a bound of exactly 0: the minimiser on the working set is the
+      // solution of the affine LQ problem itself (gaps c_i, gradients q_i, r_i in the recursion), so neither a state
+      // trajectory nor a gradient at z = 0 is needed first: one factorisation and one forward sweep.
+      int na = 0;
+      for (int i = tid; i < nv; i += 64) { S[L.rho + i] = S[L.r0 + i]; na += S[L.act + i] != TQ(0) ? 1 : 0; }
+      nact = wave_sum(na);
       __syncthreads();
+      PF_START();
+      TQ gfac = 0;
+      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac);
+      PF_STOP(PF_FACTOR);
+      if (!fok) return false;
+      gm = tmax(TQ(1), gfac);
+      tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
+      tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;
+      refactor = false;
+      PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+      dx_done = true;
+    } else if (full) {
+      // the last pass took a full Newton step with an unchanged working set: the state trajectory is affine in z
+      if (!dx_done) {
+        for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
+        __syncthreads();
+      }
+      dx_done = false;
       if (sizeof(TQ) == 8 && nact == 0) { settled = true; break; }   // no multipliers to check, step exact to f64 rounding
       PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
     } else {
+      dx_done = false;
       for (int i = tid; i < nv; i += 64) {
         const TQ a = S[L.act + i];
         if (a < 0) S[L.z + i] = S[L.lb + i];
@@ -1113,6 +1193,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
       }
     }
     fresh = false;
+    if (!aff) {
     // stationarity on the free set, worst multiplier sign violation on the pinned set
     TQ gF = 0, vmax = 0;
     int na = 0;
@@ -1153,7 +1234,8 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
     if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, L); PF_STOP(PF_FACTOR); if (!fok) return false; }
     else { riccati_backward_vec<C>(m, S, A, L, true); PF_STOP(PF_BWD); }
     refactor = false;
-    PF_START(); riccati_forward<C>(m, S, A, L, L.dz); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+    }
     TQ alpha = 1;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
@@ -1204,13 +1286,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
   if (try_warm && m.warm_max > 0) {
-    for (int i = tid; i < nv; i += 64) S[L.z + i] = 0;
-    __syncthreads();
-    PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-    PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
-    for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
-    gm = wave_max(gm);
-    if (polish<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // settles right after a rollout of the final z
+    if (polish<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // sets z = 0 and its own gradient scale
       *status = 0;
       return wpasses;
     }
@@ -1312,7 +1388,6 @@ __device__ inline long chunk_row(int j, int have, int idx, int skip, int len) { 
 
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
-  extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
   const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
@@ -1349,35 +1424,37 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   };
   auto uref = [&](int i, int k) -> double { return (mode & MODE_TRAJ) ? m.uref[k] : gy[i * NY + NX + k]; };
   TQ* gmu = st.mu + (size_t)b * 3 * nb;
-  if (gp) {
-    // alpha = Kx^-1 mu  (the OCP model evaluates k*(v_b) Kx^-1 p, src/gp/RGP.py:250-254)
-    for (int i = tid; i < 3 * nb; i += 64) {
-      const int d = i / nb, r = i % nb;
-      const TQ* kr = m.Kxinv + d * nb * nb + r * nb;
-      const TQ* mu = gmu + d * nb;
-      TQ t = 0;
-      int k = 0;
-      for (; k + 5 <= nb; k += 5) {
-        const TQ a0 = kr[k], a1 = kr[k + 1], a2 = kr[k + 2], a3 = kr[k + 3], a4 = kr[k + 4];
-        const TQ b0 = mu[k], b1 = mu[k + 1], b2 = mu[k + 2], b3 = mu[k + 3], b4 = mu[k + 4];
-        t += a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3 + a4 * b4;
-      }
-      for (; k < nb; ++k) t += kr[k] * mu[k];
-      S[L.alpha + i] = t;
-      S[L.basis + i] = m.basis[i];
-    }
-  }
-  if (tid < NX) D[L.x0 + tid] = st.x_meas[(size_t)b * NX + tid];
-  // X -> LDS and qv = Q_i (X_i - xref_i) in one pass over the record
+  // Every independent global load of the phase is issued before the first use, so the phase costs about one
+  // memory round trip (plus the cursor, which the reference rows depend on).
   constexpr int UNR = 5;
-  for (int base = 0; base < (N + 1) * NX; base += 64 * UNR) {
-    double xv[UNR], rv[UNR];
+  constexpr bool keep_ref = C::N > 0 && (C::N + 1) * NX <= 64 * UNR;   // reference rows stay in registers for the cost
+  double xv[UNR], rv[UNR];
+  auto load_block = [&](int base) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int it = base + u * 64 + tid, itc = it < (N + 1) * NX ? it : 0, i = itc / NX;
       xv[u] = gX[itc];
       rv[u] = xref(i, itc - i * NX);
     }
+  };
+  load_block(0);
+  const double xm = tid < NX ? st.x_meas[(size_t)b * NX + tid] : 0.0;
+  if (gp) {   // mu -> LDS scratch (shooting records are not live yet); rows of Kx^-1 come straight from L2
+    for (int i = tid; i < 3 * nb; i += 64) { S[L.sub + i] = gmu[i]; S[L.basis + i] = m.basis[i]; }
+  }
+  // U -> LDS, r0 = R (U_i - uref_i), bounds
+  for (int it = tid; it < nv; it += 64) {
+    const int i = it >> 2, k = it & 3;
+    const double u = gU[it];
+    D[L.U + it] = u;
+    S[L.r0 + it] = (TQ)(m.h * m.W[NX + k] * (u - uref(i, k)));
+    S[L.lb + it] = (TQ)(m.ulb[k] - u);
+    S[L.ub + it] = (TQ)(m.uub[k] - u);
+  }
+  if (tid < NX) D[L.x0 + tid] = xm;
+  // X -> LDS and qv = Q_i (X_i - xref_i) in one pass over the record
+  for (int base = 0; base < (N + 1) * NX; base += 64 * UNR) {
+    if (base > 0) load_block(base);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int it = base + u * 64 + tid;
@@ -1395,19 +1472,22 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     S[L.wq + VS + tid] = tid < NX ? (TQ)m.We[i2o(tid)] : TQ(0);
     S[L.wq + 2 * VS + tid] = tid < NU ? (TQ)(m.h * m.W[NX + tid]) : TQ(0);
   }
-  // U -> LDS, r0 = R (U_i - uref_i), bounds
-  for (int it = tid; it < nv; it += 64) {
-    const int i = it >> 2, k = it & 3;
-    const double u = gU[it];
-    D[L.U + it] = u;
-    S[L.r0 + it] = (TQ)(m.h * m.W[NX + k] * (u - uref(i, k)));
-    S[L.lb + it] = (TQ)(m.ulb[k] - u);
-    S[L.ub + it] = (TQ)(m.uub[k] - u);
-  }
-  if (mode & MODE_TRAJ) {  // expose the chunk like set_reference_trajectory's return value
-    double* oy = st.yref + (size_t)b * N * NY;
-    for (int it = tid; it < N * NY; it += 64) { const int i = it / NY, k = it - i * NY; oy[it] = k < NX ? xref(i, k) : m.uref[k - NX]; }
-    if (tid < NX) st.yrefN[(size_t)b * NX + tid] = xref(N, tid);
+  if (gp) {
+    __syncthreads();
+    // alpha = Kx^-1 mu  (the OCP model evaluates k*(v_b) Kx^-1 p, src/gp/RGP.py:250-254)
+    for (int i = tid; i < 3 * nb; i += 64) {
+      const int d = i / nb, r = i - d * nb;
+      const TQ* kr = m.Kxinv + d * nb * nb + r * nb;
+      const TQ* mu = S + L.sub + d * nb;
+      TQ t = 0;
+      int k = 0;
+      for (; k + 5 <= nb; k += 5) {
+        const TQ a0 = kr[k], a1 = kr[k + 1], a2 = kr[k + 2], a3 = kr[k + 3], a4 = kr[k + 4];
+        t += a0 * mu[k] + a1 * mu[k + 1] + a2 * mu[k + 2] + a3 * mu[k + 3] + a4 * mu[k + 4];
+      }
+      for (; k < nb; ++k) t += kr[k] * mu[k];
+      S[L.alpha + i] = t;
+    }
   }
   __syncthreads();
   PF_STOP(PF_LOAD);
@@ -1441,11 +1521,24 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   // cost at the new iterate (get_cost)
   double cst = 0;
   int bad = 0;
-  for (int it = tid; it < (N + 1) * NX; it += 64) {
-    const int i = it / NX, k = it - i * NX;
-    const double v = D[L.X + it], e = v - xref(i, k);
-    cst += 0.5 * (i < N ? m.h * m.W[k] : m.We[k]) * e * e;
-    if (!(v == v)) bad = 1;
+  if (keep_ref) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int it = u * 64 + tid;
+      if (it < (N + 1) * NX) {
+        const int i = it / NX, k = it - i * NX;
+        const double v = D[L.X + it], e = v - rv[u];
+        cst += 0.5 * (i < N ? m.h * m.W[k] : m.We[k]) * e * e;
+        if (!(v == v)) bad = 1;
+      }
+    }
+  } else {
+    for (int it = tid; it < (N + 1) * NX; it += 64) {
+      const int i = it / NX, k = it - i * NX;
+      const double v = D[L.X + it], e = v - xref(i, k);
+      cst += 0.5 * (i < N ? m.h * m.W[k] : m.We[k]) * e * e;
+      if (!(v == v)) bad = 1;
+    }
   }
   for (int it = tid; it < nv; it += 64) {
     const double v = D[L.U + it], e = v - uref(it >> 2, it & 3);
@@ -1528,7 +1621,6 @@ __global__ void predict_kernel(const DevModel<TQ> m, const double* x, const doub
 
 template <typename TQ>
 __global__ void regress_kernel(const DevModel<TQ> m, const DevState<TQ> st, const double* vb, const double* ad) {
-  extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
   const Lds L = lds_layout(m.N, m.nb, m.gab);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
   const int b = blockIdx.x;
@@ -1551,8 +1643,7 @@ __global__ void plant_kernel(const DevModel<TQ> m, double* xs, const double* w, 
 }
 
 // reduce per-instance statistics to 5 numbers (sum, sum, sum, max, #failed)
-__global__ void stats_kernel(const double* stats, const int* status, int B, double* out5) {
-  extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base)
+static __global__ void stats_kernel(const double* stats, const int* status, int B, double* out5) {
   double (*sh)[256] = reinterpret_cast<double (*)[256]>(smem_raw);  // [5][256]
   double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {

@@ -2,6 +2,7 @@
 #include <ucontext.h>
 
 #include <chrono>
+#include <cstring>
 #include <cstdio>
 #include <vector>
 
@@ -37,7 +38,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
   if (shmem > sizeof(mpcq::smem_raw)) { fprintf(stderr, "emu: shared memory request too large\n"); abort(); }
   fibers.resize(nt);
   body_ptr = &body;
+  static const bool poison = getenv("MPCQ_EMU_POISON") != nullptr;
   for (unsigned b = 0; b < grid.x; ++b) {
+    if (poison) std::memset(mpcq::smem_raw, 0xFF, sizeof(mpcq::smem_raw));   // LDS is not initialised on the device either: all-ones = NaN
     for (int t = 0; t < nt; ++t) {
       Fiber& f = fibers[t];
       f.done = false;

@@ -61,6 +61,7 @@ inline float __expf(float x) { return std::exp(x); }
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 inline int __double2loint(double d) { uint64_t u; std::memcpy(&u, &d, 8); return (int)(uint32_t)u; }
@@ -120,6 +121,20 @@ inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool)
   else if (ctrl >= 0x121 && ctrl <= 0x12F) src = (t & ~15u) | ((t - (unsigned)(ctrl - 0x120)) & 15u);
   else { std::abort(); }
   const int r = (int)(uint32_t)ex[src];
+  emu::sync();
+  return r;
+}
+// v_permlane32_swap_b32 (gfx950): lanes 32..63 of `a` are exchanged with lanes 0..31 of `b`; returns {new a, new b}
+typedef unsigned emu_u2 __attribute__((ext_vector_type(2)));
+inline emu_u2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+  uint64_t* ea = emu::exchange();
+  uint64_t* eb = emu::exchange2();
+  const unsigned t = emu::cur->tid.x, w = t & ~63u, l = t & 63u;
+  ea[t] = a; eb[t] = b;
+  emu::sync();
+  emu_u2 r;
+  r[0] = l < 32 ? a : (unsigned)eb[w + l - 32];
+  r[1] = l < 32 ? (unsigned)ea[w + l + 32] : b;
   emu::sync();
   return r;
 }

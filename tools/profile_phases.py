@@ -14,6 +14,7 @@ from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspac
 from mpc_quad_ros_amd.trajectories import swarm_trajectories  # noqa: E402
 
 NAMES = ["load", "shoot_x", "shoot_s", "factor", "fwd", "bwd", "adjoint", "rollout", "elem", "post", "total"]
+FINE = {11: "fwd: loads/shift", 12: "fwd: K Dx chain", 13: "fwd: broadcast", 14: "fwd: A Dx chain"}
 
 
 def main():
@@ -45,6 +46,9 @@ def main():
     print(f"{'phase':10s} {'mean cycles':>12s} {'share':>7s} {'slowest-quad cycles':>20s}")
     for i, n in enumerate(NAMES):
         print(f"{n:10s} {mean[i]:12.0f} {100 * mean[i] / mean[10]:6.1f}% {mxs[i]:20.0f}")
+    for k, n in FINE.items():
+        if mean[k] > 0:
+            print(f"  {n:18s} {mean[k]:12.0f}")
     other = mean[10] - mean[:10].sum()
     print(f"{'other':10s} {other:12.0f} {100 * other / mean[10]:6.1f}%")
 
