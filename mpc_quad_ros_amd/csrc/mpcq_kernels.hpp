@@ -26,6 +26,13 @@
 
 namespace mpcq {
 
+// unroll factors of the stage loops (factorisation / vector sweeps); the shape-specialised translation unit sets its own
+#ifndef MPCQ_UNROLL_FACTOR
+#define MPCQ_UNROLL_FACTOR 1
+#endif
+#ifndef MPCQ_UNROLL_SWEEP
+#define MPCQ_UNROLL_SWEEP 1
+#endif
 constexpr int NX = 13, NU = 4, NY = 17;
 constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
 constexpr int VS = 16;           // stride of state-sized QP vectors (internal order, 13 used)
@@ -654,6 +661,7 @@ __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
     vl_load(S + L.vin + id * VS, h, qz[d]);
     vl_load(A + L.c + id * VS, h, qc[d]);
   }
+#pragma unroll MPCQ_UNROLL_SWEEP
   for (int i = 0; i < N; ++i) {
     const int ip = i + PD < N ? i + PD : N - 1;
     rm.load(A, ip, qa[PD]);
@@ -698,6 +706,7 @@ __device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
     km.load(A, id, qa[d]);
     vl_load(A + L.qv + id * VS, h, qq[d]);
   }
+#pragma unroll MPCQ_UNROLL_SWEEP
   for (int i = N - 1; i >= 0; --i) {
     const int ip = i - PD > 0 ? i - PD : 0;
     km.load(A, ip, qa[PD]);
@@ -732,6 +741,7 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A,
   TQ pv[4] = {0, 0, 0, 0}, qa[PD + 1][4];
 #pragma unroll
   for (int d = 0; d < PD; ++d) km.load(A, N - 1 - d > 0 ? N - 1 - d : 0, qa[d]);
+#pragma unroll MPCQ_UNROLL_SWEEP
   for (int i = N - 1; i >= 0; --i) {
     km.load(A, i - PD > 0 ? i - PD : 0, qa[PD]);
     TQ rv[4], acc[4] = {0, 0, 0, 0};
@@ -782,6 +792,7 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
   }
   rk.load(S, 0, kc);
   vl_load(S + L.vin, h, kv);
+#pragma unroll MPCQ_UNROLL_SWEEP
   for (int i = 0; i < N; ++i) {
     const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1;
     rm.load(A, ig, qa[PD]);
@@ -888,6 +899,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
   km.load(A, N - 1, cur);
   if (lane < VS) S[L.spv + lane] = 0;
   __syncthreads();
+#pragma unroll MPCQ_UNROLL_FACTOR
   for (int i = N - 1; i >= 0; --i) {
     km.load(A, i > 0 ? i - 1 : 0, nxt);   // a factorisation stage is long enough to hide one global fetch
     TQ qvi = 0;
