@@ -132,6 +132,11 @@ void* mpcq_stream(mpcq_engine* e);   /* hipStream_t the engine launches on */
  * mpcq_sim_steps runs K closed-loop iterations {step(x) -> plant} without host round trips. */
 int mpcq_sim_reset(mpcq_engine* e, const double* x0);
 int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt);
+/* The same K closed-loop iterations as ONE launch in which every instance runs through its K control periods
+ * without waiting for the others (instances are independent; src/execute_trajectory.py:196-279 is a loop over ONE
+ * quadrotor).  Same arithmetic, same results as mpcq_sim_steps; the per-period outputs readable afterwards
+ * (mpcq_get_*, mpcq_sim_get_state) are those of the last period. */
+int mpcq_sim_run(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt);
 int mpcq_sim_get_state(mpcq_engine* e, double* x /*[B,13]*/, double* w /*[B,4] or NULL*/);
 /* HIP-event time of the step-kernel launches of the last mpcq_sim_steps call (events recorded on
  * the engine's stream around every launch): total seconds and number of launches. */

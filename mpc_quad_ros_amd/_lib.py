@@ -40,6 +40,7 @@ SYMBOLS = [
     ("mpcq_stream", _vp, [_vp]),
     ("mpcq_sim_reset", ctypes.c_int, [_vp, _dp]),
     ("mpcq_sim_steps", ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
+    ("mpcq_sim_run", ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
     ("mpcq_sim_get_state", ctypes.c_int, [_vp, _dp, _dp]),
     ("mpcq_get_kernel_time", ctypes.c_int, [_vp, _dp, _ip]),
     ("mpcq_get_tracking_stats", ctypes.c_int, [_vp, _dp]),

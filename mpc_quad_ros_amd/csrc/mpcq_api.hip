@@ -16,11 +16,11 @@
 
 namespace mpcq {   // mpcq_spec.hip
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
-StepFn<double> spec_step_f64(int N, int nb, bool gab);
-StepFn<float> spec_step_f32(int N, int nb, bool gab);
+StepFn<double> spec_step_f64(int N, int nb, bool gab, bool run);
+StepFn<float> spec_step_f32(int N, int nb, bool gab, bool run);
 }
-static mpcq::StepFn<double> spec_step(int N, int nb, bool gab, double*) { return mpcq::spec_step_f64(N, nb, gab); }
-static mpcq::StepFn<float> spec_step(int N, int nb, bool gab, float*) { return mpcq::spec_step_f32(N, nb, gab); }
+static mpcq::StepFn<double> spec_step(int N, int nb, bool gab, bool run, double*) { return mpcq::spec_step_f64(N, nb, gab, run); }
+static mpcq::StepFn<float> spec_step(int N, int nb, bool gab, bool run, float*) { return mpcq::spec_step_f32(N, nb, gab, run); }
 
 namespace {
 
@@ -130,6 +130,7 @@ struct mpcq_engine {
   virtual int step_device(const void*, void*) = 0;
   virtual int sim_reset(const double*) = 0;
   virtual int sim_steps(int, int, double) = 0;
+  virtual int sim_run(int, int, double) = 0;
   virtual int sim_get(double*, double*) = 0;
   virtual int stats(double*) = 0;
   virtual int get_prof(unsigned long long*) = 0;
@@ -146,6 +147,7 @@ struct EngineT : mpcq_engine {
   mpcq::Lds L;
   size_t lds_bytes = 0;
   void (*kstep)(const mpcq::DevModel<T>, const mpcq::DevState<T>, const int) = nullptr;
+  void (*krun)(const mpcq::DevModel<T>, const mpcq::DevState<T>, const int) = nullptr;   // free-running variant (mpcq_sim_run)
   std::vector<double> hbufd;
   T *d_basis = nullptr, *d_Kxinv = nullptr, *d_Kx = nullptr;
   double *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr, *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
@@ -299,8 +301,12 @@ struct EngineT : mpcq_engine {
     if (gab && (rc = dalloc(st.stage, Bz * L.gtotal))) return rc;
     kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false>>;
     // shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
-    if (!getenv("MPCQ_GENERIC"))
-      if (auto k = spec_step(N, nb, gab, (T*)nullptr)) kstep = k;
+    krun = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false, 0, -1, true>>;
+    if (!getenv("MPCQ_GENERIC")) {
+      if (auto k = spec_step(N, nb, gab, false, (T*)nullptr)) kstep = k;
+      if (auto k = spec_step(N, nb, gab, true, (T*)nullptr)) krun = k;
+    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::regress_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     return reset();
@@ -462,6 +468,27 @@ struct EngineT : mpcq_engine {
     }
     return 0;
   }
+  int sim_run(int K, int n_sub, double sim_dt) override {
+    if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_sim_run needs mpcq_set_trajectories first");
+    if (K <= 0) return 0;
+    mpcq::DevState<T> s2 = st;
+    s2.x_meas = d_xs;
+    s2.run_x = d_xs; s2.run_steps = K; s2.run_nsub = n_sub; s2.run_dt = sim_dt;
+    while ((int)kev.size() < 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
+    HIP_TRY(hipEventRecord(ev0, stream));
+    HIP_TRY(hipEventRecord(kev[0], stream));
+    hipLaunchKernelGGL(krun, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST | mpcq::MODE_RUN);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(kev[1], stream));
+    HIP_TRY(hipEventRecord(ev1, stream));
+    timed = true;
+    HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, kev[0], kev[1]));
+    ktime = ms * 1e-3;
+    klaunches = 1;
+    return 0;
+  }
   int sim_get(double* x, double* w) override {
     int rc;
     if ((rc = d2h(x, d_xs, (size_t)B * 13))) return rc;
@@ -579,6 +606,7 @@ int mpcq_synchronize(mpcq_engine* e) { CHK(e); HIP_TRY(hipStreamSynchronize(e->s
 void* mpcq_stream(mpcq_engine* e) { return e ? (void*)e->stream : nullptr; }
 int mpcq_sim_reset(mpcq_engine* e, const double* x0) { CHK(e); return e->sim_reset(x0); }
 int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { CHK(e); return e->sim_steps(K, n_sub, sim_dt); }
+int mpcq_sim_run(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { CHK(e); return e->sim_run(K, n_sub, sim_dt); }
 int mpcq_sim_get_state(mpcq_engine* e, double* x, double* w) { CHK(e); return e->sim_get(x, w); }
 int mpcq_get_kernel_time(mpcq_engine* e, double* s, int32_t* n) { CHK(e); if (s) *s = e->ktime; if (n) *n = e->klaunches; return 0; }
 int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]) { CHK(e); return e->stats(out); }

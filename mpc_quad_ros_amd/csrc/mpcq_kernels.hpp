@@ -41,7 +41,7 @@ constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded 
 constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
 constexpr int SUBS = 4 * SUBW + 1;  // per-stage stride of the records (odd: lanes of different stages hit different banks)
 
-enum : int { MODE_TRAJ = 1, MODE_POST = 2 };
+enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4 };   // MODE_RUN: free-running closed loop, DevState::run_* periods per launch
 
 // Diagnostic build only (-DMPCQ_PROFILE, libmpcq_prof.so): per-phase shader-cycle totals per instance.
 enum : int { PF_LOAD = 0, PF_SHOOT_X, PF_SHOOT_S, PF_FACTOR, PF_FWD, PF_BWD, PF_ADJ, PF_ROLL, PF_ELEM, PF_POST, PF_TOTAL, PF_N = 16 };
@@ -108,6 +108,9 @@ struct DevState {
   int* status;
   int* qp_iter;
   TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
+  double* run_x;    // [B][13] plant states of the free-running closed loop (MODE_RUN; aliases x_meas)
+  int run_steps, run_nsub;   // control periods per launch, plant substeps per period
+  double run_dt;    // plant substep
   unsigned long long* prof;   // [B][PF_N] (diagnostic build only)
 };
 
@@ -186,6 +189,16 @@ template <typename T> struct alignas(16) V4 { T a, b, c, d; };
 template <typename T> __device__ inline T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> __device__ inline T tmax(T a, T b) { return a > b ? a : b; }
 
+// Lane index as an opaque value: everything derived from it (tile coordinates, masks, operand offsets) is then
+// recomputed where it is used instead of being hoisted to the top of the kernel and kept in registers through all
+// phases (and through every period of the free-running variant).
+__device__ inline int lane_id() {
+  int t = threadIdx.x;
+#if defined(__AMDGCN__)
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
 // lane broadcast: `lane` must be wave-uniform (a constant after unrolling) -> v_readlane_b32 into an SGPR
 __device__ inline int bc(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ inline float bc(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
@@ -203,7 +216,7 @@ template <int CTRL> __device__ inline double dpp(double v) {
 __device__ inline int xrow2(int v) {
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   const u2 r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-  return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+  return (int)((lane_id() & 32) ? r[0] : r[1]);
 }
 __device__ inline float xrow2(float v) { return __int_as_float(xrow2(__float_as_int(v))); }
 __device__ inline double xrow2(double v) { return __hiloint2double(xrow2(__double2hiint(v)), xrow2(__double2loint(v))); }
@@ -508,9 +521,10 @@ __device__ inline void plant_rk4(const M& m, double* x, const double* uin, doubl
 // One step-kernel instantiation per Cfg.  N = 0 / NB = -1 read the horizon and the RGP basis size from the
 // model at run time (any shape); fixed values turn every LDS offset, trip count and index division into a
 // compile-time constant for the shapes that matter (see mpcq_api.hip for the table of instances).
-template <typename T_, bool GAB_, int N_ = 0, int NB_ = -1> struct Cfg {
+template <typename T_, bool GAB_, int N_ = 0, int NB_ = -1, bool RUN_ = false> struct Cfg {
   using T = T_;
   static constexpr bool GAB = GAB_;
+  static constexpr bool RUN = RUN_;   // free-running closed loop: the kernel iterates over control periods
   static constexpr int N = N_, NB = NB_;
 };
 template <typename C, typename M> __device__ inline int cN(const M& m) { return C::N > 0 ? C::N : m.N; }
@@ -521,7 +535,7 @@ template <typename C, typename M> __device__ inline int cNB(const M& m) { return
 // (the part X_i - X_{i+1} of the gap is formed in double)
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* A, const Lds& L, bool gp) {
-  const int N = cN<C>(m), lane = threadIdx.x;
+  const int N = cN<C>(m), lane = lane_id();
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
   // with the GP in the model the three axis sums (nb exps each) of a stage go to three neighbouring lanes
@@ -568,7 +582,7 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds
   const TQ w_s[4] = {TQ(1), TQ(2), TQ(2), TQ(1)};
   const TQ c10 = (qc.J[1] - qc.J[2]) * qc.iJ[0], c11 = (qc.J[2] - qc.J[0]) * qc.iJ[1], c12 = (qc.J[0] - qc.J[1]) * qc.iJ[2];
   const TQ tm = qc.tmax * qc.imass;
-  for (int it = threadIdx.x; it < N * 14; it += 64) {
+  for (int it = lane_id(); it < N * 14; it += 64) {
     const int i = it / 14, jp = it - i * 14, j = 3 + jp;
     const bool ucol = j >= NX;
     TQ Sp[NX], acc[NX], Z[NX];
@@ -612,8 +626,8 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds
     for (int r = 0; r < NX; ++r) AB[o2i(r) * ABW + jp] = ((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r];
   }
   // zero the two pad columns (read by the vectorised 4-wide loads)
-  for (int it = threadIdx.x; it < N * NX * 2; it += 64) A[L.AB + (it >> 1) * ABW + 14 + (it & 1)] = 0;
-  for (int it = threadIdx.x; it < N * 3; it += 64) A[L.c + (it / 3) * VS + NX + it % 3] = 0;
+  for (int it = lane_id(); it < N * NX * 2; it += 64) A[L.AB + (it >> 1) * ABW + 14 + (it & 1)] = 0;
+  for (int it = lane_id(); it < N * 3; it += 64) A[L.c + (it / 3) * VS + NX + it % 3] = 0;
 }
 
 // ------------------------------------------------------------------ QP: vector sweeps
@@ -645,7 +659,7 @@ __host__ __device__ inline int GI(int i) { return (i >> 2) * VS + 10 + (i & 3); 
 // forward rollout dx_{i+1} = A dx_i + B z_i (+ c_i); dx_0 taken from S[dxo + 0..15]
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dxo, int zo, bool with_c) {
-  const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[zo + i];
   __syncthreads();
@@ -686,7 +700,7 @@ __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 // adjoint sweep: grad = d/dz of the QP objective at (dx(z), z)
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
-  const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
   __syncthreads();
@@ -731,7 +745,7 @@ __device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 // backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, bool polish) {
-  const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15, nv = N * NU;
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
   const Sel<TQ> sel(h);
@@ -776,7 +790,7 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A,
 // state trajectory to S[L.dx] (z_i = K_i dx_i + k_i to S[dzo])
 template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
-  const int N = cN<C>(m), lane = threadIdx.x, h = lane >> 4, c = lane & 15;
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   const Sel<TQ> sel(h);
   const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c), rk(L.zb, L.K, KS, NU, h, c);
@@ -855,7 +869,7 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr) {
-  const int N = cN<C>(m), lane = threadIdx.x, nv = N * NU, h = lane >> 4, c = lane & 15;
+  const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
   // stage input Hessian diagonals R~ (negative value = input pinned by the polish)
@@ -1049,7 +1063,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
 // mu <= tol.  returns 0 converged / 1 NaN / 2 iteration cap / 4 stage Hessian not positive definite
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
-  const int N = cN<C>(m), nv = N * NU, tid = threadIdx.x;
+  const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int status = 2;
   const int maxit = m.qp_max_iter;
   for (; it < maxit; ++it) {
@@ -1142,7 +1156,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
   bool fresh = false;
-  const int N = cN<C>(m), nv = N * NU, tid = threadIdx.x;
+  const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
     for (int i = tid; i < nv; i += 64) {
       S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
@@ -1294,7 +1308,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int* status, const bool try_warm PF_ARG) {
-  const int N = cN<C>(m), nv = N * NU, tid = threadIdx.x;
+  const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
   if (try_warm && m.warm_max > 0) {
@@ -1343,7 +1357,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 //   mu += G (y - mu_p) ; C -= G (J C)      (not symmetrised, as in the reference)
 template <typename C, typename TQ = typename C::T>
 __device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu, TQ* gC, const double* vb, const double* ad, bool c_staged = false) {
-  const int n = cNB<C>(m), tid = threadIdx.x, NT = blockDim.x, n3 = 3 * n, nn = n * n;
+  const int n = cNB<C>(m), tid = lane_id(), NT = blockDim.x, n3 = 3 * n, nn = n * n;
   TQ* Cw = S + L.rgp;
   TQ* ks = Cw + al4(3 * nn);
   TQ* Jt = ks + al4(n3);
@@ -1400,7 +1414,7 @@ __device__ inline long chunk_row(int j, int have, int idx, int skip, int len) { 
 
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = lane_id();
   const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
   const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
   double* D = reinterpret_cast<double*>(smem_raw);
@@ -1414,6 +1428,10 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   const unsigned long long t_begin = __builtin_readcyclecounter();
   pf.t = t_begin;
 #endif
+  // MODE_RUN: this workgroup advances its quadrotor through run_steps control periods {step -> drag plant} on its
+  // own: instances are independent, so nothing forces the batch to wait for its slowest member every period.
+  const int periods = C::RUN ? st.run_steps : 1;
+  for (int period = 0; period < periods; ++period) {
   // ---- load persistent state (lane-contiguous records) and form the QP data in double.  All global
   //      loads of a block are issued before the first use so their latencies overlap.
   double* gX = st.X + (size_t)b * (N + 1) * NX;
@@ -1563,7 +1581,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; }
   if (tid < NU) st.w[(size_t)b * NU + tid] = D[L.U + tid];
   PF_START();
-  if (!(mode & MODE_POST)) return;
+  if (mode & MODE_POST) {
   // ---- 4. post: nominal prediction, cursor, drag estimate, RGP regress, statistics
   double* vbad = D + L.x0 + NX;   // [v_body(3), a_drag(3)]
   if (gp) {   // stage the covariance while lane 0 integrates the nominal model (QP workspace is dead)
@@ -1608,6 +1626,21 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   }
   __syncthreads();
   if (gp) rgp_regress<C>(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3, true);
+  }
+  if (C::RUN) {   // the plant produces the next measurement (plant_kernel of the lockstep path)
+    if (tid == 0) {
+      double x[NX], u[NU];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) x[k] = st.run_x[(size_t)b * NX + k];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) u[k] = D[L.U + k];
+      for (int sub = 0; sub < st.run_nsub; ++sub) plant_rk4(m, x, u, st.run_dt);
+#pragma unroll
+      for (int k = 0; k < NX; ++k) st.run_x[(size_t)b * NX + k] = x[k];
+    }
+  }
+  __syncthreads();
+  }   // periods
 #ifdef MPCQ_PROFILE
   PF_STOP(PF_POST);
   pf.acc[PF_TOTAL] = __builtin_readcyclecounter() - t_begin;

@@ -11,13 +11,14 @@ namespace mpcq {
 
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
 
-template <typename T> static StepFn<T> pick(int N, int nb, bool gab) {
+template <typename T, bool RUN> static StepFn<T> pick(int N, int nb, bool gab) {
   if (N == 20 && nb == 10)   // BASELINE configs[1]
-    return gab ? &step_kernel<Cfg<T, true, 20, 10>> : &step_kernel<Cfg<T, false, 20, 10>>;
+    return gab ? &step_kernel<Cfg<T, true, 20, 10, RUN>> : &step_kernel<Cfg<T, false, 20, 10, RUN>>;
   return nullptr;
 }
 
-StepFn<double> spec_step_f64(int N, int nb, bool gab) { return pick<double>(N, nb, gab); }
-StepFn<float> spec_step_f32(int N, int nb, bool gab) { return pick<float>(N, nb, gab); }
+// run = the free-running closed-loop variant (mpcq_sim_run)
+StepFn<double> spec_step_f64(int N, int nb, bool gab, bool run) { return run ? pick<double, true>(N, nb, gab) : pick<double, false>(N, nb, gab); }
+StepFn<float> spec_step_f32(int N, int nb, bool gab, bool run) { return run ? pick<float, true>(N, nb, gab) : pick<float, false>(N, nb, gab); }
 
 }  // namespace mpcq

@@ -146,6 +146,10 @@ class Engine:
     def sim_steps(self, K, n_sub, sim_dt=5e-3):
         self._check(self.lib.mpcq_sim_steps(self.h, int(K), int(n_sub), float(sim_dt)))
 
+    def sim_run(self, K, n_sub, sim_dt=5e-3):
+        """K closed-loop periods in one launch, every instance advancing on its own (same results as sim_steps)."""
+        self._check(self.lib.mpcq_sim_run(self.h, int(K), int(n_sub), float(sim_dt)))
+
     def sim_get_state(self):
         x = np.zeros((self.B, NX))
         w = np.zeros((self.B, NU))

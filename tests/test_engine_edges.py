@@ -112,7 +112,33 @@ def _reference_format_log(lib):
     assert np.isclose(np.sqrt(st[0] / (3 * st[2])), np.sqrt(np.mean(rms ** 2)), rtol=1e-9)
 
 
-CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log]
+def _free_running_equals_lockstep(lib):
+    """mpcq_sim_run (one launch, every instance runs its K periods on its own) must reproduce mpcq_sim_steps
+    (one launch per period) bit for bit: state, controls, cursors, RGP posterior, tracking statistic.  Ragged
+    trajectory lengths so that some instances run past the end of their reference inside the launch."""
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    big = lib is None
+    B, N, nb, K = (64, 20, 10, 40) if big else (3, 20, 10, 9)
+    traj, lens = swarm_trajectories(5, 0, B)
+    lens = lens.copy(); lens[0] = 6
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    for precision in (0, 1):
+        res = []
+        for mode in ("sim_steps", "sim_run"):
+            e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision), lib_path=lib)
+            e.set_trajectories(traj, lens); e.sim_reset(x0)
+            getattr(e, mode)(K, 2, 5e-3)
+            getattr(e, mode)(2, 2, 5e-3)            # a second call continues where the first stopped
+            st = e.get_state()
+            mu, C = e.get_rgp()
+            res.append([*e.sim_get_state(), st["X"], st["U"], st["idx"], mu, C, e.get_tracking_stats(), e.get_status(), e.get_cost()])
+            e.close()
+        for a, b in zip(*res):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+        assert (res[0][4] == K + 2).all()
+
+
+CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log, _free_running_equals_lockstep]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.__name__.strip("_") for c in CASES])

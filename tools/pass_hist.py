@@ -27,3 +27,7 @@ fb = sum(v for k, v in hist.items() if k >= 1000)
 print("fallback share", fb / tot, "steps with >=1 fallback", sum(1 for m in permax if m >= 1000), "of", steps)
 kt = np.array(kt) * 1e3
 print("kernel ms: mean %.3f  with-fallback mean %.3f  no-fallback mean %.3f" % (kt.mean(), kt[np.array(permax) >= 1000].mean() if any(m >= 1000 for m in permax) else 0, kt[np.array(permax) < 1000].mean()))
+pm = np.array(permax) % 1000
+for v in sorted(set(pm.tolist())):
+    sel = (pm == v) & (np.array(permax) < 1000)
+    if sel.any(): print("launches whose slowest instance took %d passes: %d, kernel ms mean %.4f" % (v, sel.sum(), kt[sel].mean()))
