@@ -283,14 +283,12 @@ __device__ inline void vl_store(double* base, int h, const double (&v)[4]) {
 // k-major operand: lane (h,c) <- AB''[RI(s,h)][c]
 template <typename TQ> struct KMaj {
   int off[4], str[4];
-  // with_gap: pad column 14 of the operand carries the gap c_i (so that P c comes out of the product P AB'' for free)
-  __device__ inline KMaj(const Lds& L, int N, int h, int c, bool with_gap = false) {
+  __device__ inline KMaj(const Lds& L, int N, int h, int c) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int k = RI<TQ>(s, h);
       off[s] = k < NX ? L.AB + k * ABW + c : L.AB + N * ABS + c;
       str[s] = k < NX ? ABS : 0;
-      if (with_gap && c == 14 && k < NX) { off[s] = L.c + k; str[s] = VS; }
     }
   }
   __device__ inline void load(const TQ* P, int i, TQ (&o)[4]) const {
@@ -786,7 +784,7 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A,
 }
 
 // forward sweep: Dx_0 = 0; dz_i = K_i Dx_i + k_i ; Dx_{i+1} = A Dx_i + B dz_i   (out: S[dzo], S[L.Dx])
-// affine: the sweep of the affine recursion instead: starts from dx_0 in S[L.dx], adds the gaps c_i and writes the
+// affine: the sweep of the affine recursion instead: starts from dx_0 in S[L.dx], adds the gaps (S[L.Dx]) and writes the
 // state trajectory to S[L.dx] (z_i = K_i dx_i + k_i to S[dzo])
 template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
@@ -802,7 +800,7 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
 #pragma unroll
   for (int d = 0; d < PD; ++d) {
     rm.load(A, d < N ? d : N - 1, qa[d]);
-    if (affine) vl_load(A + L.c + (d < N ? d : N - 1) * VS, h, qc[d]);
+    if (affine) vl_load(S + L.Dx + (d < N ? d : N - 1) * VS, h, qc[d]);
   }
   rk.load(S, 0, kc);
   vl_load(S + L.vin, h, kv);
@@ -810,7 +808,7 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
   for (int i = 0; i < N; ++i) {
     const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1;
     rm.load(A, ig, qa[PD]);
-    if (affine) vl_load(A + L.c + ig * VS, h, qc[PD]);
+    if (affine) vl_load(S + L.Dx + ig * VS, h, qc[PD]);
     rk.load(S, ip, kn);
     vl_load(S + L.vin + ip * VS, h, kvn);
     PF_FINE(11);
@@ -882,7 +880,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
   }
   for (int it = lane; it < N * NU * 3; it += 64) S[L.K + (it / 3) * ABW + NX + it % 3] = 0;   // K pad columns
   const Sel<TQ> sel(h);
-  const KMaj<TQ> km(L, N, h, c, affine);
+  const KMaj<TQ> km(L, N, h, c);
   // P_N = W_e as an accumulator tile: Pop[s] = P[RI(s,h)][c]; per-lane masks for the assembly of Q + G
   TQ Pop[4], pv[4] = {0, 0, 0, 0}, qdg[4], mA2[4], mA1[4], mPo[4], mT[4], gmax = 0;
   if (affine) vl_load(A + L.qv + N * VS, h, pv);   // p_N = q_N
@@ -910,12 +908,22 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
   const int o4str = lane < NX ? ABW : 1;
   const TQ o4sgn = lane < NX ? TQ(-1) : TQ(1), tbm = lane < NX ? TQ(1) : TQ(0);
   TQ cur[4], nxt[4];
+  // affine: pad column 14 of the operand carries the gap (S[L.Dx], prepared by the caller), so that P c comes out of the
+  // product P AB'' for free
+  auto with_gap = [&](int st, TQ (&x)[4]) {
+    TQ gq[4];
+    vl_load(S + L.Dx + st * VS, h, gq);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = vl ? gq[s] : x[s];
+  };
   km.load(A, N - 1, cur);
+  if (affine) with_gap(N - 1, cur);
   if (lane < VS) S[L.spv + lane] = 0;
   __syncthreads();
 #pragma unroll MPCQ_UNROLL_FACTOR
   for (int i = N - 1; i >= 0; --i) {
     km.load(A, i > 0 ? i - 1 : 0, nxt);   // a factorisation stage is long enough to hide one global fetch
+    if (affine) with_gap(i > 0 ? i - 1 : 0, nxt);
     TQ qvi = 0;
     if (affine) qvi = A[L.qv + i * VS + b3];   // consumed at the end of the stage
     TQ acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
@@ -1155,6 +1163,156 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+  const int N = cN<C>(m), nv = N * NU, tid = lane_id();
+  if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
+    for (int i = tid; i < nv; i += 64) {
+      S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
+      S[L.z + i] = 0;
+    }
+  } else {      // working set identified by the interior point
+    for (int i = tid; i < nv; i += 64)
+      S[L.act + i] = S[L.ll + i] > S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > S[L.su + i] ? TQ(1) : TQ(0));
+  }
+  __syncthreads();
+  TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
+  TQ tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
+  const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
+  bool refactor = true, settled = false;
+  int nact = 1;   // pinned inputs in the working set
+  bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
+  bool dx_done = false;   // the forward sweep already produced the state trajectory (affine pass)
+  TQ gF_prev = TQ(1e30);
+  for (passes = 0; passes < max_passes; ++passes) {
+    const bool aff = refactor;
+    if (aff) {
+      // New working set.  Its minimiser is the solution of the affine LQ problem with the pinned inputs held at their
+      // bounds: their effect B_i zbar_i joins the gap c_i, the stage gradients q_i, r_i enter the vector recursion
+      // directly -- ONE masked factorisation and ONE forward sweep, whatever the current point is (no state rollout,
+      // no gradient sweep first).
+      int na = 0;
+      for (int i = tid; i < nv; i += 64) {
+        const TQ a = S[L.act + i];
+        if (a < 0) S[L.z + i] = S[L.lb + i];
+        else if (a > 0) S[L.z + i] = S[L.ub + i];
+        S[L.rho + i] = S[L.r0 + i];
+        na += a != TQ(0) ? 1 : 0;
+      }
+      nact = wave_sum(na);
+      __syncthreads();
+      for (int it = tid; it < N * VS; it += 64) {
+        const int i = it >> 4, r = it & 15;
+        TQ v = 0;
+        if (r < NX) {
+          v = A[L.c + it];
+          if (nact > 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j)
+              if (S[L.act + i * NU + j] != TQ(0)) v += A[L.AB + i * ABS + r * ABW + 10 + j] * S[L.z + i * NU + j];
+          }
+        }
+        S[L.Dx + it] = v;
+      }
+      __syncthreads();
+      PF_START();
+      TQ gfac = 0;
+      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac);
+      PF_STOP(PF_FACTOR);
+      if (!fok) return false;
+      gm = tmax(TQ(1), gfac);
+      tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
+      tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;
+      refactor = false;
+      gF_prev = TQ(1e30);
+      PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+      // the sweep returns the minimiser itself: turn it into a step from the current point for the ratio test below
+      for (int i = tid; i < nv; i += 64)
+        if (S[L.act + i] == TQ(0)) S[L.dz + i] -= S[L.z + i];
+      __syncthreads();
+      dx_done = true;
+    } else {
+      // the last pass took a full step on an unchanged working set: the point minimises the QP on it (to rounding)
+      if (!dx_done) {
+        for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
+        __syncthreads();
+      }
+      dx_done = false;
+      if (sizeof(TQ) == 8 && nact == 0) { settled = true; break; }   // no multipliers to check, step exact to f64 rounding
+      PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
+      // stationarity on the free set, worst multiplier sign violation on the pinned set
+      TQ gF = 0, vmax = 0;
+      for (int i = tid; i < nv; i += 64) {
+        const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
+        if (a == TQ(0)) gF = tmax(gF, tabs(g));
+        else vmax = tmax(vmax, a < 0 ? -g : g);
+      }
+      gF = wave_max(gF);
+      vmax = wave_max(vmax);
+      if (!(gF == gF)) return false;
+#ifdef MPCQ_EMU_DEBUG
+      if (tid == 0) printf("  polish pass %d warm %d gF %.3e vmax %.3e tolm %.3e tols %.3e nact %d\n", passes, (int)warm, (double)gF, (double)vmax, (double)tolm, (double)tols, nact);
+#endif
+      if (vmax > tolm) {   // multipliers are meaningful at a minimiser of the working set only: here
+        for (int i = tid; i < nv; i += 64) {
+          const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
+          const TQ v = a < 0 ? -g : g;
+          if (a != TQ(0) && (careful ? v >= vmax : v > tolm)) S[L.act + i] = 0;   // release wrong-signed multipliers (all, or the worst)
+        }
+        refactor = true;
+        released = true;
+        __syncthreads();
+        continue;
+      }
+      if (gF <= tols || gF > TQ(0.25) * gF_prev) {
+        settled = true;  // stationary to rounding, or the Newton refinement stagnated at the rounding level
+        break;
+      }
+      gF_prev = gF;
+      // Newton refinement on the unchanged working set with the stored factors
+      for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
+      __syncthreads();
+      PF_START(); riccati_backward_vec<C>(m, S, A, L, true); PF_STOP(PF_BWD);
+      PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+    }
+    TQ alpha = 1;
+    for (int i = tid; i < nv; i += 64) {
+      if (S[L.act + i] != TQ(0)) continue;
+      const TQ d = S[L.dz + i], z = S[L.z + i];
+      if (d < 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.lb + i] - z) / d));
+      if (d > 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.ub + i] - z) / d));
+    }
+    alpha = wave_min(alpha);
+    // full step; if it leaves the box, clip and pin EVERY violator at once (the minimiser on a working set does not
+    // depend on the starting point, so only the sequence of working sets matters)
+    int nblk = 0;
+    for (int i = tid; i < nv; i += 64) {
+      if (S[L.act + i] != TQ(0)) continue;
+      const TQ lb = S[L.lb + i], ub = S[L.ub + i];
+      TQ z = S[L.z + i] + S[L.dz + i];
+      if (alpha < TQ(1)) {
+        if (z <= lb + tolb) { z = lb; S[L.act + i] = -1; nblk += 1; }
+        else if (z >= ub - tolb) { z = ub; S[L.act + i] = 1; nblk += 1; }
+      }
+      S[L.z + i] = z;
+    }
+    nblk = wave_sum(nblk);
+#ifdef MPCQ_EMU_DEBUG
+    if (tid == 0) printf("     pass %d aff %d alpha %.6e nblk %d\n", passes, (int)aff, (double)alpha, nblk);
+#endif
+    if (nblk > 0) { refactor = true; if (released) careful = true; }
+    released = false;
+    __syncthreads();
+  }
+  if (settled && sizeof(TQ) == 4) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
+    PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+  }
+  return settled;
+}
+
+// The same active-set method with Newton steps from the current point after every change of the working set (a state
+// rollout and a gradient sweep first): used for TQ = float, where increments keep their accuracy while a from-scratch
+// affine solve would have to be refined again every time.
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
+__device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
   bool fresh = false;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
@@ -1184,6 +1342,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
       int na = 0;
       for (int i = tid; i < nv; i += 64) { S[L.rho + i] = S[L.r0 + i]; na += S[L.act + i] != TQ(0) ? 1 : 0; }
       nact = wave_sum(na);
+      for (int it = tid; it < N * VS; it += 64) S[L.Dx + it] = (it & 15) < NX ? A[L.c + it] : TQ(0);   // gap of the affine pass (all pinned inputs sit at 0)
       __syncthreads();
       PF_START();
       TQ gfac = 0;
@@ -1312,7 +1471,8 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
   if (try_warm && m.warm_max > 0) {
-    if (polish<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // sets z = 0 and its own gradient scale
+    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)
+                        : polish_incremental<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // sets z = 0 and its own gradient scale
       *status = 0;
       return wpasses;
     }
@@ -1337,7 +1497,8 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
-    if (polish<C>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
+    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)
+                        : polish_incremental<C>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
