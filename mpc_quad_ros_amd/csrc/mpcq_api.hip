@@ -298,7 +298,7 @@ struct EngineT : mpcq_engine {
     if (getenv("MPCQ_VERBOSE")) fprintf(stderr, "mpcq: stage records in %s, LDS %zu B per instance (%zu per CU), lds-only layout %zu B (%zu per CU)\n", gab ? "global memory" : "LDS", gab ? bg : bl, gab ? occ_g : occ_l, bl, occ_l);
     L = gab ? Lg : Ll;
     lds_bytes = gab ? bg : bl;
-    if (gab && (rc = dalloc(st.stage, Bz * L.gtotal))) return rc;
+    if ((rc = dalloc(st.stage, Bz * L.gtotal))) return rc;   // stage records (global placement) + multiplier rows
     kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false>>;
     // shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
     krun = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false, 0, -1, true>>;

@@ -37,6 +37,7 @@ constexpr int NX = 13, NU = 4, NY = 17;
 constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
 constexpr int VS = 16;           // stride of state-sized QP vectors (internal order, 13 used)
 constexpr int ABS = NX * ABW;    // per-stage stride of AB'
+constexpr int MROW = 20;          // stride of a multiplier row (see Lds::mrow)
 constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded to 16)
 constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
 constexpr int SUBS = 4 * SUBW + 1;  // per-stage stride of the records (odd: lanes of different stages hit different banks)
@@ -126,6 +127,7 @@ struct Lds {
   int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv, spv;
   int sub, rgp, qtotal;
   int gab, zb, gx, gtotal;   // stage data (AB'', c, qv) in global memory? ; LDS zero block ; GP exchange scratch ; global elements per instance
+  int mrow;                  // multiplier rows (always global): per stage 4 rows [M_a(13) | F_uu row(4) | gt_a | pad 2]
 };
 __host__ __device__ inline int al4(int v) { return (v + 3) & ~3; }
 __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
@@ -153,6 +155,7 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
     L.zb = L.AB + N * ABS;
     L.gx = L.AB;   // exchange scratch of shoot_states: AB'' is not written before shoot_sens
   }
+  L.mrow = gtake(N * MROW * NU);
   L.gtotal = (g + 15) & ~15;
   L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv);
   L.alpha = take(3 * nb);
@@ -866,7 +869,7 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr) {
+__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr, TQ* mrows = nullptr) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
@@ -1011,8 +1014,17 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
       for (int j = 0; j < 4; ++j) {
         const TQ mv = S[m3off + j * m3str];
         y[j] = mk[j] * (lane < NX ? mv : ((lane - NX) == j ? TQ(1) : TQ(0)));
-        g[j] = mk[j] * (S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j]);   // gt = rho + B^T p
+        const TQ gu = S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j];     // gt = rho + B^T p
+        g[j] = mk[j] * gu;
         if (affine) gmax = tmax(gmax, tabs(g[j]));
+        if (affine && mrows && mk[j] == TQ(0)) {   // what the multiplier of a pinned input j needs: [M_j | F_uu row j | gt_j]
+          if (lane < NX) mrows[(i * NU + j) * MROW + lane] = mv;
+          else if (lane - NX == j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mrows[(i * NU + j) * MROW + NX + q] = S[L.sF + j * VS + 10 + q];
+            mrows[(i * NU + j) * MROW + NX + 4] = gu;
+          }
+        }
       }
 #pragma unroll
       for (int cc = 1; cc < 4; ++cc) {
@@ -1162,7 +1174,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
     for (int i = tid; i < nv; i += 64) {
@@ -1175,13 +1187,10 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
   }
   __syncthreads();
   TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
-  TQ tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
   bool refactor = true, settled = false;
   int nact = 1;   // pinned inputs in the working set
   bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
-  bool dx_done = false;   // the forward sweep already produced the state trajectory (affine pass)
-  TQ gF_prev = TQ(1e30);
   for (passes = 0; passes < max_passes; ++passes) {
     const bool aff = refactor;
     if (aff) {
@@ -1215,72 +1224,70 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
       __syncthreads();
       PF_START();
       TQ gfac = 0;
-      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac);
+      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac, nact > 0 ? G + L.mrow : nullptr);
       PF_STOP(PF_FACTOR);
       if (!fok) return false;
       gm = tmax(TQ(1), gfac);
       tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
-      tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;
       refactor = false;
-      gF_prev = TQ(1e30);
       PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
       // the sweep returns the minimiser itself: turn it into a step from the current point for the ratio test below
       for (int i = tid; i < nv; i += 64)
         if (S[L.act + i] == TQ(0)) S[L.dz + i] -= S[L.z + i];
       __syncthreads();
-      dx_done = true;
     } else {
       // the last pass took a full step on an unchanged working set: the point minimises the QP on it (to rounding)
-      if (!dx_done) {
-        for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
-        __syncthreads();
+      if (nact == 0) { settled = true; break; }   // no multipliers to check, the step is exact to rounding
+      // Multipliers of the pinned inputs without a gradient sweep: with the cost-to-go of the factorisation,
+      // lambda_a = gt_a + M_a dx_i + sum_{q free} (B'PB)_aq z_q + R_aa z_a  (rows left behind by riccati_factor)
+      TQ vmax = 0;
+      for (int i = tid; i < nv; i += 64) {
+        const TQ a = S[L.act + i];
+        TQ lam = 0;
+        if (a != TQ(0)) {
+          const int st = i >> 2, j = i & 3;
+          const TQ* row = G + L.mrow + i * MROW;
+          TQ rv[NX + 5];
+#pragma unroll
+          for (int k = 0; k < NX + 5; ++k) rv[k] = row[k];
+          lam = rv[NX + 4] + S[L.wq + 2 * VS + j] * S[L.z + i];
+#pragma unroll
+          for (int k = 0; k < NX; ++k) lam += rv[k] * S[L.dx + st * VS + k];
+#pragma unroll
+          for (int q = 0; q < NU; ++q)
+            if (q != j && S[L.act + st * NU + q] == TQ(0)) lam += rv[NX + q] * S[L.z + st * NU + q];
+          vmax = tmax(vmax, a < 0 ? -lam : lam);
+        }
+        S[L.grad + GI(i)] = lam;
       }
-      dx_done = false;
-      if (sizeof(TQ) == 8 && nact == 0) { settled = true; break; }   // no multipliers to check, step exact to f64 rounding
-      PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
-      // stationarity on the free set, worst multiplier sign violation on the pinned set
-      TQ gF = 0, vmax = 0;
+      vmax = wave_max(vmax);
+      if (!(vmax == vmax)) return false;
+#ifdef MPCQ_EMU_DEBUG
+      if (tid == 0) printf("  polish pass %d warm %d vmax %.3e tolm %.3e nact %d\n", passes, (int)warm, (double)vmax, (double)tolm, nact);
+#endif
+      if (vmax <= tolm) { settled = true; break; }
+      __syncthreads();
       for (int i = tid; i < nv; i += 64) {
         const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
-        if (a == TQ(0)) gF = tmax(gF, tabs(g));
-        else vmax = tmax(vmax, a < 0 ? -g : g);
+        const TQ v = a < 0 ? -g : g;
+        if (a != TQ(0) && (careful ? v >= vmax : v > tolm)) S[L.act + i] = 0;   // release wrong-signed multipliers (all, or the worst)
       }
-      gF = wave_max(gF);
-      vmax = wave_max(vmax);
-      if (!(gF == gF)) return false;
-#ifdef MPCQ_EMU_DEBUG
-      if (tid == 0) printf("  polish pass %d warm %d gF %.3e vmax %.3e tolm %.3e tols %.3e nact %d\n", passes, (int)warm, (double)gF, (double)vmax, (double)tolm, (double)tols, nact);
-#endif
-      if (vmax > tolm) {   // multipliers are meaningful at a minimiser of the working set only: here
-        for (int i = tid; i < nv; i += 64) {
-          const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
-          const TQ v = a < 0 ? -g : g;
-          if (a != TQ(0) && (careful ? v >= vmax : v > tolm)) S[L.act + i] = 0;   // release wrong-signed multipliers (all, or the worst)
-        }
-        refactor = true;
-        released = true;
-        __syncthreads();
-        continue;
-      }
-      if (gF <= tols || gF > TQ(0.25) * gF_prev) {
-        settled = true;  // stationary to rounding, or the Newton refinement stagnated at the rounding level
-        break;
-      }
-      gF_prev = gF;
-      // Newton refinement on the unchanged working set with the stored factors
-      for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
+      refactor = true;
+      released = true;
       __syncthreads();
-      PF_START(); riccati_backward_vec<C>(m, S, A, L, true); PF_STOP(PF_BWD);
-      PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+      continue;
     }
     TQ alpha = 1;
+    int nanf = 0;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
       const TQ d = S[L.dz + i], z = S[L.z + i];
+      if (!(d == d)) nanf = 1;
       if (d < 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.lb + i] - z) / d));
       if (d > 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.ub + i] - z) / d));
     }
     alpha = wave_min(alpha);
+    if (wave_max(nanf)) return false;
     // full step; if it leaves the box, clip and pin EVERY violator at once (the minimiser on a working set does not
     // depend on the starting point, so only the sequence of working sets matters)
     int nblk = 0;
@@ -1466,12 +1473,12 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int* status, const bool try_warm PF_ARG) {
+__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const bool try_warm PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
   if (try_warm && m.warm_max > 0) {
-    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)
+    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, m.warm_max PF_PASS)
                         : polish_incremental<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // sets z = 0 and its own gradient scale
       *status = 0;
       return wpasses;
@@ -1497,7 +1504,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
-    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)
+    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, passes, false, m.polish_max PF_PASS)
                         : polish_incremental<C>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
@@ -1580,8 +1587,9 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
   double* D = reinterpret_cast<double*>(smem_raw);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
+  TQ* G = st.stage + (size_t)b * L.gtotal;   // per-instance record in global memory
   TQ* A = S;   // base of the stage records
-  if (GAB) A = st.stage + (size_t)b * L.gtotal;
+  if (GAB) A = G;
   const bool gp = nb > 0;
 #ifdef MPCQ_PROFILE
   Prof pf;
@@ -1696,7 +1704,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  const int iters = solve_qp<C>(m, S, A, L, &status, st.qp_iter[b] > 0 PF_PASS);
+  const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b] > 0 PF_PASS);
   // ---- 3. full step (iterate accumulated in double)
   for (int it = tid; it < (N + 1) * NX; it += 64) {
     const int i = it / NX, k = it - i * NX;
