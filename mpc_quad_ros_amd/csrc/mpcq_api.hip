@@ -211,10 +211,10 @@ struct EngineT : mpcq_engine {
     m.qp_tol = (T)(c.qp_tol > 0 ? c.qp_tol : (f32 ? 2e-6 : 1e-11));
     m.eps = f32 ? (T)6e-8 : (T)1.1e-16;
     m.ipm_tol = f32 ? (T)1e-4 : (T)1e-6;
-    m.polish_max = f32 ? 12 : 8;
+    m.polish_max = f32 ? 12 : 16;   // fp64 passes alternate between a multiplier check and an affine solve: twice the count of fp32's
     if (const char* t = getenv("MPCQ_IPM_TOL")) m.ipm_tol = (T)atof(t);
     if (const char* t = getenv("MPCQ_POLISH_MAX")) m.polish_max = atoi(t);
-    m.warm_max = f32 ? 12 : 12;   // passes of the warm active-set attempt before falling back to the IPM
+    m.warm_max = f32 ? 12 : 24;   // passes of the warm active-set attempt before falling back to the IPM
     if (const char* t = getenv("MPCQ_WARM_MAX")) m.warm_max = atoi(t);
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;
     m.h = c.T / c.N; m.dt_pred = c.dt_pred;

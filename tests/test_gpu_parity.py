@@ -169,3 +169,29 @@ def test_device_closed_loop_matches_host_driven_loop():
             x = o.plant_update(x, w, 5e-3)
     xe, we = e.sim_get_state()
     assert np.abs(xe - x).max() < 1e-7 and np.abs(we - w).max() < 1e-7
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_whole_trajectories_full_batch(precision):
+    """BASELINE configs[1] at full size over the whole 9 s references (900 control periods): every instance keeps
+    solving (status 0 on the last period, tracking error bounded) and the free-running launch reproduces the
+    per-period launches bit for bit."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N, nb = 1024, 20, 10
+    traj, lens = swarm_trajectories(2026, 0, B)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    out = []
+    for mode in ("sim_steps", "sim_run"):
+        e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision))
+        e.set_trajectories(traj, lens)
+        e.sim_reset(x0)
+        getattr(e, mode)(900, 2, 5e-3)
+        st = e.get_tracking_stats()
+        assert (e.get_status() == 0).all()
+        assert st[2] == 900 * B and st[4] == 0
+        assert np.sqrt(st[0] / (3 * st[2])) < 0.05 and np.sqrt(st[3]) < 1.0     # rms / worst position error [m]
+        out.append((e.sim_get_state(), e.get_state()["X"], st))
+        e.close()
+    assert np.array_equal(out[0][0][0], out[1][0][0]) and np.array_equal(out[0][0][1], out[1][0][1])
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
