@@ -16,8 +16,8 @@ P = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(O, pattern), recursive=True)
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(O, pattern), recursive=True), key=os.path.getmtime)
+    return g[-1] if g else None   # newest run of that tag
 
 
 bench = json.loads(open(os.path.join(O, f"bench_{TAG}.json")).read().strip().splitlines()[-1])
