@@ -161,7 +161,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    ktime, klaunch = e.get_kernel_time()     # HIP events around every step_kernel launch of the timed region
+    ktime, klaunch = e.get_kernel_time()     # HIP events around a sample (every 4th) of the step_kernel launches of the timed region
     its = e.get_qp_iter()
     status = e.get_status()
     if dist is not None:
@@ -202,7 +202,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": f"mpcq::step_kernel<{'double' if prec == PRECISION_F64 else 'float'}>",
-                         "kernel_avg_ms": 1e3 * k_avg, "kernel_launches": klaunch,
+                         "kernel_avg_ms": 1e3 * k_avg, "kernel_launches": args.steps, "kernel_launches_timed": klaunch,
+                         "timing": "HIP events on the engine's stream around every 4th step-kernel launch of the timed region (MPCQ_KEV_STRIDE)",
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "path is latency/VALU/LDS bound, not HBM bound (DESIGN.md): secondary figure below",
                          "vector_flops": {"achieved_tflops": flops_launch / k_avg / 1e12,

@@ -138,8 +138,9 @@ int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt);
  * (mpcq_get_*, mpcq_sim_get_state) are those of the last period. */
 int mpcq_sim_run(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt);
 int mpcq_sim_get_state(mpcq_engine* e, double* x /*[B,13]*/, double* w /*[B,4] or NULL*/);
-/* HIP-event time of the step-kernel launches of the last mpcq_sim_steps call (events recorded on
- * the engine's stream around every launch): total seconds and number of launches. */
+/* HIP-event time of the step-kernel launches of the last mpcq_sim_steps / mpcq_sim_run call (events recorded on
+ * the engine's stream around every 4th launch, MPCQ_KEV_STRIDE=1 for every launch): total seconds of the timed
+ * launches and their number. */
 int mpcq_get_kernel_time(mpcq_engine* e, double* seconds, int32_t* launches);
 
 /* ---- tracking statistic (src/Visualiser.py:787-789,809-811,918), summed over this engine's

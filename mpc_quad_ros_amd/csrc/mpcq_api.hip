@@ -447,12 +447,18 @@ struct EngineT : mpcq_engine {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_sim_steps needs mpcq_set_trajectories first");
     mpcq::DevState<T> s2 = st;
     s2.x_meas = d_xs;
-    while ((int)kev.size() < 2 * K) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
+    // HIP events around every `stride`-th step-kernel launch (an event pair costs a few microseconds of dispatch
+    // overlap, so only a sample of the launches carries one; MPCQ_KEV_STRIDE=1 times every launch)
+    int stride = 4;
+    if (const char* t = getenv("MPCQ_KEV_STRIDE")) stride = atoi(t) > 0 ? atoi(t) : 1;
+    const int nev = (K + stride - 1) / stride;
+    while ((int)kev.size() < 2 * nev) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
     HIP_TRY(hipEventRecord(ev0, stream));
     for (int k = 0; k < K; ++k) {
-      HIP_TRY(hipEventRecord(kev[2 * k], stream));
+      const bool timed_launch = k % stride == 0;
+      if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride)], stream));
       hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
-      HIP_TRY(hipEventRecord(kev[2 * k + 1], stream));
+      if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride) + 1], stream));
       hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, sim_dt, B);
     }
     HIP_TRY(hipGetLastError());
@@ -460,8 +466,8 @@ struct EngineT : mpcq_engine {
     timed = true;
     HIP_TRY(hipStreamSynchronize(stream));
     ktime = 0;
-    klaunches = K;
-    for (int k = 0; k < K; ++k) {
+    klaunches = nev;
+    for (int k = 0; k < nev; ++k) {
       float ms = 0;
       HIP_TRY(hipEventElapsedTime(&ms, kev[2 * k], kev[2 * k + 1]));
       ktime += ms * 1e-3;
