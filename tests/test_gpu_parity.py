@@ -195,3 +195,25 @@ def test_whole_trajectories_full_batch(precision):
         e.close()
     assert np.array_equal(out[0][0][0], out[1][0][0]) and np.array_equal(out[0][0][1], out[1][0][1])
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_config2_full_size():
+    """BASELINE configs[2] at full size (8 192 quadrotors, 20 RGP basis points per axis; any-shape kernel instance, eight
+    rounds of workgroups): both launch modes agree bit for bit, every instance solves, controls respect the box."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N, nb, K = 8192, 20, 20, 40
+    traj, lens = swarm_trajectories(7, 0, B)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    out = []
+    for mode in ("sim_steps", "sim_run"):
+        e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb)))
+        e.set_trajectories(traj, lens)
+        e.sim_reset(x0)
+        getattr(e, mode)(K, 2, 5e-3)
+        assert (e.get_status() == 0).all()
+        x, w = e.sim_get_state()
+        assert w.min() >= 0.0 and w.max() <= 1.0 and np.isfinite(x).all()
+        out.append((x, w, e.get_tracking_stats()))
+        e.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
