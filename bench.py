@@ -253,8 +253,8 @@ def main():
             k2, l2 = e2.get_kernel_time()
             out["alt_precision"] = {"dtype": alt, "value": B * args.steps / (tb - ta), "unit": "control steps/s",
                                     "kernel_avg_ms": 1e3 * k2 / max(l2, 1),
-                                    "note": "same workload with the QP arithmetic in the other precision (f32: 4 quadrotors resident per CU, "
-                                            "parity ~1e-5 typical / 1e-4 worst; f64: 2 per CU, parity ~1e-10)"}
+                                    "note": "same workload with the QP arithmetic in the other precision (f32: parity ~1e-5 typical / 1e-4 worst, "
+                                            "all-LDS working set; f64: parity ~1e-10, stage records in global memory; both 4 quadrotors per CU)"}
             e2.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, nb, args.seed)

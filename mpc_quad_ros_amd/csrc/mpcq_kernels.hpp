@@ -1,11 +1,12 @@
 // mpcq_kernels.hpp — device code of the batched MPC+RGP control step (gfx950 / CDNA4).
 //
-// One quadrotor per 64-lane wavefront (one workgroup = one wave).  All per-instance working
-// data (iterate, shooting sensitivities, Riccati gains, IPM vectors, RGP covariance) is staged in
-// LDS; HBM is touched once per step to load and once to store the persistent state, with
-// lane-contiguous (coalesced) records.  Short vectors of the Riccati / adjoint / rollout
-// recursions live in registers (lane a holds component a) and are broadcast with lane reads, so the
-// N-stage sweeps run without LDS round trips or barriers on their critical path.
+// One quadrotor per 64-lane wavefront (one workgroup = one wave).  The per-instance working set lives in
+// LDS (iterate, Riccati gains, QP vectors, RGP covariance, shooting records); the per-stage records
+// (sensitivities AB'', shooting gaps, cost gradients) live in LDS or, when that lets the whole batch be
+// resident at once, in a per-instance global record streamed through L2 (Cfg::GAB).  HBM is touched once
+// per step to load and once to store the persistent state, with lane-contiguous (coalesced) records.
+// The vectors of the Riccati / adjoint / rollout recursions ride in pad column 14 of the matrix-core tiles,
+// so the N-stage sweeps run without LDS round trips or barriers on their critical path.
 //
 // Precision: the SQP iterate (X, U), the measurement, the reference and every difference that
 // defines the QP data (x0 - X0, X_i - xref_i, U_i - uref_i, bounds, shooting gaps) are formed in
@@ -15,11 +16,12 @@
 // Algorithm (same mathematical step as the reference's acados SQP-RTI call, restated in
 // SURVEY App. A; not a translation of acados/HPIPM code):
 //   1. multiple shooting: explicit RK4 (1 step) with forward sensitivities per interval
-//   2. box-QP in du: Mehrotra predictor-corrector IPM to a hand-over tolerance, then an
-//      active-set polish (Newton on the free set + ratio test) to an exact KKT point; every
-//      Newton system is one Riccati factorisation of the stage-sparse problem
-//      (O(N) memory, well conditioned; the condensed Hessian is never formed)
+//   2. box-QP in du on the stage-sparse problem (O(N) memory; the condensed Hessian is never formed):
+//      warm active-set method from the previous step's working set -- per working set ONE masked Riccati
+//      factorisation + ONE forward sweep of the affine LQ problem (polish); cold start / cycling: Mehrotra
+//      predictor-corrector IPM to a hand-over tolerance, then the same active-set iterations to an exact KKT point
 //   3. full step, cost, nominal RK4 prediction, body-frame drag estimate, 3 scalar RGP updates.
+// Cfg::RUN instances iterate steps 1-3 plus the drag plant over many control periods in one launch.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
