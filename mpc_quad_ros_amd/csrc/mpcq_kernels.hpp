@@ -35,6 +35,12 @@ namespace mpcq {
 #ifndef MPCQ_UNROLL_SWEEP
 #define MPCQ_UNROLL_SWEEP 1
 #endif
+// fp32 QP: free-set stationarity (in units of eps * gradient scale) below which no refinement pass is attempted.
+// Measured on MI355X: 1 -> 8 takes the mean pass count from 2.5 to 1.7 (+16 % throughput) with the same worst-case
+// control deviation on the parity tests (1.3e-5); 32 and above let it grow to 7e-5.
+#ifndef MPCQ_F32_TOLS
+#define MPCQ_F32_TOLS 8
+#endif
 constexpr int NX = 13, NU = 4, NY = 17;
 constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
 constexpr int VS = 16;           // stride of state-sized QP vectors (internal order, 13 used)
@@ -1335,7 +1341,7 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
   }
   __syncthreads();
   TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
-  TQ tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
+  TQ tols = (sizeof(TQ) == 4 ? TQ(MPCQ_F32_TOLS) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
   bool refactor = true, settled = false, full = false;
   int nact = 1;   // pinned inputs in the working set (unknown before the first count)
@@ -1360,7 +1366,7 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
       if (!fok) return false;
       gm = tmax(TQ(1), gfac);
       tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
-      tols = (sizeof(TQ) == 4 ? TQ(1) : TQ(64)) * m.eps * gm;
+      tols = (sizeof(TQ) == 4 ? TQ(MPCQ_F32_TOLS) : TQ(64)) * m.eps * gm;
       refactor = false;
       PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
       dx_done = true;
