@@ -1347,6 +1347,7 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
   int nact = 1;   // pinned inputs in the working set (unknown before the first count)
   bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
   bool dx_done = false;   // the forward sweep already produced the state trajectory (affine pass)
+  bool incremental = false;   // the state trajectory has been updated by increments since it was last computed from z
   TQ gF_prev = TQ(1e30);
   for (passes = 0; passes < max_passes; ++passes) {
     const bool aff = warm && passes == 0;
@@ -1375,6 +1376,7 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
       if (!dx_done) {
         for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
         __syncthreads();
+        incremental = true;
       }
       dx_done = false;
       if (sizeof(TQ) == 8 && nact == 0) { settled = true; break; }   // no multipliers to check, step exact to f64 rounding
@@ -1390,6 +1392,7 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
       if (!fresh) {
         PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
         PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
+        incremental = false;
       }
     }
     fresh = false;
@@ -1466,7 +1469,7 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
     released = false;
     __syncthreads();
   }
-  if (settled && sizeof(TQ) == 4) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
+  if (settled && sizeof(TQ) == 4 && incremental) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
     PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
   }
   return settled;
