@@ -93,6 +93,27 @@ def cpu_baseline(N, nb, seed, budget_s=15.0):
             "us_per_step_per_core": 1e6 * t_step * cores / (B * steps)}
 
 
+def call_with_timeout(fn, seconds=90.0):
+    """Run fn() in a daemon thread; (True, result) or (False, exception / 'timeout').  A collective that never returns
+    (a rank that died, a fabric problem) must not take the whole bench line with it."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except Exception as ex:      # noqa: BLE001
+            box["e"] = ex
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return False, "timeout"
+    if "e" in box:
+        return False, box["e"]
+    return True, box.get("r")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,7 +131,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("MPCQ_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # MPCQ_BENCH_DEVICE: testing aid (several ranks on one GPU)
     dist = None
     if world > 1:
         import torch.distributed as dist  # host-side rendezvous only (barrier, max, id broadcast)
@@ -123,23 +144,23 @@ def main():
     itemsize = 8 if prec == PRECISION_F64 else 4
     e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed)
     stats_reduce = "single"
+    rccl_hung = False
     if world > 1:
         # the only collective of the path: RCCL all-reduce of the 5-number swarm statistic inside libmpcq.so.
         # If RCCL cannot be brought up on this node the statistic is reduced over the host group instead
         # (and the bench line says so); the timed region has no collective either way.
         stats_reduce = "rccl"
-        try:
-            uid = [e.comm_unique_id() if rank == 0 else None]
-        except Exception as ex:          # noqa: BLE001
-            uid = [f"ERR {ex}"]
+        rccl_hung = False
+        okid, rid = call_with_timeout(lambda: e.comm_unique_id() if rank == 0 else None)
+        uid = [rid if okid else f"ERR {rid}"]
         dist.broadcast_object_list(uid, src=0)
         ok = 1
         if isinstance(uid[0], (bytes, bytearray)):
-            try:
-                e.comm_init(rank, world, uid[0])
-            except Exception as ex:      # noqa: BLE001
+            okc, rc = call_with_timeout(lambda: e.comm_init(rank, world, uid[0]))
+            if not okc:
                 ok = 0
-                print(f"# rank {rank}: RCCL init failed: {ex}", file=sys.stderr)
+                rccl_hung = rc == "timeout"
+                print(f"# rank {rank}: RCCL init failed: {rc}", file=sys.stderr)
         else:
             ok = 0
         import torch
@@ -169,9 +190,18 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+    stats = None
     if world > 1 and stats_reduce == "rccl":
-        stats = e.allreduce_tracking_stats()
-    else:
+        oks, rs = call_with_timeout(e.allreduce_tracking_stats)
+        import torch
+        flag = torch.tensor([1 if oks else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            stats = rs
+        else:
+            rccl_hung = rccl_hung or rs == "timeout"
+            stats_reduce = "gloo (RCCL all-reduce failed)"
+    if stats is None:
         stats = e.get_tracking_stats()
         if world > 1:
             import torch
@@ -262,6 +292,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        if rccl_hung:            # a thread is still blocked inside RCCL: skip the destructors
+            sys.stdout.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":
