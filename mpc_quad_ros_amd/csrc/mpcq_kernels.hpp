@@ -45,6 +45,7 @@ constexpr int NX = 13, NU = 4, NY = 17;
 constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
 constexpr int VS = 16;           // stride of state-sized QP vectors (internal order, 13 used)
 constexpr int ABS = NX * ABW;    // per-stage stride of AB'
+constexpr int PST = 256 + VS;     // stride of a stored cost-to-go (see Lds::pst)
 constexpr int MROW = 20;          // stride of a multiplier row (see Lds::mrow)
 constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded to 16)
 constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
@@ -136,6 +137,7 @@ struct Lds {
   int sub, rgp, qtotal;
   int gab, zb, gx, gtotal;   // stage data (AB'', c, qv) in global memory? ; LDS zero block ; GP exchange scratch ; global elements per instance
   int mrow;                  // multiplier rows (always global): per stage 4 rows [M_a(13) | F_uu row(4) | gt_a | pad 2]
+  int pst;                   // cost-to-go of every stage (always global): [P_i as accumulator tile (256) | p_i (16)]
 };
 __host__ __device__ inline int al4(int v) { return (v + 3) & ~3; }
 __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
@@ -164,6 +166,7 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
     L.gx = L.AB;   // exchange scratch of shoot_states: AB'' is not written before shoot_sens
   }
   L.mrow = gtake(N * MROW * NU);
+  L.pst = gtake(N * PST);
   L.gtotal = (g + 15) & ~15;
   L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv);
   L.alpha = take(3 * nb);
@@ -877,7 +880,8 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr, TQ* mrows = nullptr) {
+__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr, TQ* mrows = nullptr,
+                                      TQ* pstore = nullptr, int start = -1) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
@@ -895,6 +899,11 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
   // P_N = W_e as an accumulator tile: Pop[s] = P[RI(s,h)][c]; per-lane masks for the assembly of Q + G
   TQ Pop[4], pv[4] = {0, 0, 0, 0}, qdg[4], mA2[4], mA1[4], mPo[4], mT[4], gmax = 0;
   if (affine) vl_load(A + L.qv + N * VS, h, pv);   // p_N = q_N
+  // Restart: the recursion above the highest stage whose working set changed is unchanged, so it resumes from the
+  // cost-to-go (P_{start+1}, p_{start+1}) the previous factorisation stored (K_i, Lambda_i^-1, k_i of the stages
+  // above are still in LDS).
+  const int first = (pstore && start >= 0 && start < N - 1) ? start : N - 1;
+  const bool resumed = first < N - 1;
   int toff[4];
   const bool cq = c < 10, cp = c >= 10 && c < NX;
 #pragma unroll
@@ -902,6 +911,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
     const int row = RI<TQ>(s, h);
     const bool rq = row < 10, rp = row >= 10 && row < NX;
     Pop[s] = (row == c && c < NX) ? S[L.wq + VS + c] : TQ(0);
+    if (resumed) { Pop[s] = pstore[(first + 1) * PST + lane * 4 + s]; pv[s] = pstore[(first + 1) * PST + 256 + (row < VS ? row : 0)]; }
     qdg[s] = (row == c && c < NX) ? S[L.wq + c] : TQ(0);
     mA2[s] = (cq && rq) ? TQ(1) : TQ(0);
     mA1[s] = (cq && rp) ? TQ(1) : TQ(0);
@@ -927,12 +937,12 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
 #pragma unroll
     for (int s = 0; s < 4; ++s) x[s] = vl ? gq[s] : x[s];
   };
-  km.load(A, N - 1, cur);
-  if (affine) with_gap(N - 1, cur);
+  km.load(A, first, cur);
+  if (affine) with_gap(first, cur);
   if (lane < VS) S[L.spv + lane] = 0;
   __syncthreads();
 #pragma unroll MPCQ_UNROLL_FACTOR
-  for (int i = N - 1; i >= 0; --i) {
+  for (int i = first; i >= 0; --i) {
     km.load(A, i > 0 ? i - 1 : 0, nxt);   // a factorisation stage is long enough to hide one global fetch
     if (affine) with_gap(i > 0 ? i - 1 : 0, nxt);
     TQ qvi = 0;
@@ -1077,6 +1087,14 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
 #pragma unroll
       for (int s = 0; s < 4; ++s) { Pop[s] = C4[s]; cur[s] = nxt[s]; }
       vl_load(S + L.spv, h, pv);
+      if (pstore) {   // cost-to-go of this stage, for a later restart below it
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pstore[i * PST + lane * 4 + s] = Pop[s];
+        if (vl) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) pstore[i * PST + 256 + RI<TQ>(s, h)] = pv[s];
+        }
+      }
     }
     __syncthreads();
   }
@@ -1199,6 +1217,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
   bool refactor = true, settled = false;
   int nact = 1;   // pinned inputs in the working set
   bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
+  int top = N - 1;   // highest stage whose working set changed since the last factorisation (N-1: factorise everything)
   for (passes = 0; passes < max_passes; ++passes) {
     const bool aff = refactor;
     if (aff) {
@@ -1232,10 +1251,11 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
       __syncthreads();
       PF_START();
       TQ gfac = 0;
-      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac, nact > 0 ? G + L.mrow : nullptr);
+      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac, nact > 0 ? G + L.mrow : nullptr, G + L.pst, top);
+      top = -1;
       PF_STOP(PF_FACTOR);
       if (!fok) return false;
-      gm = tmax(TQ(1), gfac);
+      gm = tmax(gm, tmax(TQ(1), gfac));   // a restarted factorisation sees only the stages it visits
       tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
       refactor = false;
       PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
@@ -1275,11 +1295,13 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
 #endif
       if (vmax <= tolm) { settled = true; break; }
       __syncthreads();
+      int hi = -1;
       for (int i = tid; i < nv; i += 64) {
         const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
         const TQ v = a < 0 ? -g : g;
-        if (a != TQ(0) && (careful ? v >= vmax : v > tolm)) S[L.act + i] = 0;   // release wrong-signed multipliers (all, or the worst)
+        if (a != TQ(0) && (careful ? v >= vmax : v > tolm)) { S[L.act + i] = 0; hi = i >> 2; }   // release wrong-signed multipliers (all, or the worst)
       }
+      top = tmax(top, wave_max(hi));
       refactor = true;
       released = true;
       __syncthreads();
@@ -1298,18 +1320,19 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
     if (wave_max(nanf)) return false;
     // full step; if it leaves the box, clip and pin EVERY violator at once (the minimiser on a working set does not
     // depend on the starting point, so only the sequence of working sets matters)
-    int nblk = 0;
+    int nblk = 0, hip = -1;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
       const TQ lb = S[L.lb + i], ub = S[L.ub + i];
       TQ z = S[L.z + i] + S[L.dz + i];
       if (alpha < TQ(1)) {
-        if (z <= lb + tolb) { z = lb; S[L.act + i] = -1; nblk += 1; }
-        else if (z >= ub - tolb) { z = ub; S[L.act + i] = 1; nblk += 1; }
+        if (z <= lb + tolb) { z = lb; S[L.act + i] = -1; nblk += 1; hip = i >> 2; }
+        else if (z >= ub - tolb) { z = ub; S[L.act + i] = 1; nblk += 1; hip = i >> 2; }
       }
       S[L.z + i] = z;
     }
     nblk = wave_sum(nblk);
+    top = tmax(top, wave_max(hip));
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) printf("     pass %d aff %d alpha %.6e nblk %d\n", passes, (int)aff, (double)alpha, nblk);
 #endif
