@@ -1218,6 +1218,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
   int nact = 1;   // pinned inputs in the working set
   bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
   int top = N - 1;   // highest stage whose working set changed since the last factorisation (N-1: factorise everything)
+  bool keep_p = false;
   for (passes = 0; passes < max_passes; ++passes) {
     const bool aff = refactor;
     if (aff) {
@@ -1234,6 +1235,15 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
         na += a != TQ(0) ? 1 : 0;
       }
       nact = wave_sum(na);
+      if (passes == 0) {
+        // Cost-to-go tiles are kept (43 KB of global stores) only where a change of the working set is likely: some
+        // input pinned already, or a free one within `margin` of a bound.  Elsewhere a change (rare) refactorises from
+        // the top as before.
+        TQ dmin = 1;
+        for (int i = tid; i < nv; i += 64)
+          if (S[L.act + i] == TQ(0)) dmin = tmin(dmin, tmin(-S[L.lb + i], S[L.ub + i]));
+        keep_p = nact > 0 || wave_min(dmin) < TQ(0.1);
+      }
       __syncthreads();
       for (int it = tid; it < N * VS; it += 64) {
         const int i = it >> 4, r = it & 15;
@@ -1251,7 +1261,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
       __syncthreads();
       PF_START();
       TQ gfac = 0;
-      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac, nact > 0 ? G + L.mrow : nullptr, G + L.pst, top);
+      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac, nact > 0 ? G + L.mrow : nullptr, keep_p ? G + L.pst : nullptr, top);
       top = -1;
       PF_STOP(PF_FACTOR);
       if (!fok) return false;
