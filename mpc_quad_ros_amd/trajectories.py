@@ -135,3 +135,43 @@ def circle_trajectory(kind: str, radius: float, v_max: float, dt: float = 0.01, 
     x[:, 3] = 1.0
     x[:, 7:10] = np.round(v, 6)
     return x, np.round(ts, 6)
+
+
+# ---------------------------------------------------------------------------------------------
+# Piecewise-polynomial references in the format the reference's min-snap generator writes
+# (src/trajectory_generation/uav_trajectory.py:116-129: one row per piece = duration, then 8 ascending coefficients for
+# x, y, z, yaw), sampled like TrajectoryGenerator.save_evals_csv (:203-215) and read back like load_trajectory (:223-244):
+# positions / velocities rounded to the CSV's 6 decimals, q = [1,0,0,0], body rates 0.  The min-snap solve itself is a
+# prebuilt binary in the reference (genTrajectory) and is not reproduced.
+def sample_polynomial_trajectory(pieces, dt: float = 0.01):
+    pieces = np.atleast_2d(np.asarray(pieces, dtype=float))
+    if pieces.shape[1] < 33:
+        raise ValueError("a piece is [duration, x^0..x^7, y^0..y^7, z^0..z^7, yaw^0..yaw^7]")
+    dur = pieces[:, 0]
+    total = float(np.sum(dur))
+    ts = np.arange(0, total, dt)
+    x = np.zeros((len(ts), NX))
+    x[:, 3] = 1.0
+    starts = np.concatenate(([0.0], np.cumsum(dur)[:-1]))
+    for k, t in enumerate(ts):
+        # piece lookup with the reference's running sum (uav_trajectory.py:146-150)
+        cur, row, tl = 0.0, pieces[-1], t - starts[-1]
+        for r in pieces:
+            if t < cur + r[0]:
+                row, tl = r, t - cur
+                break
+            cur = cur + r[0]
+        for a in range(3):
+            c = row[1 + 8 * a:9 + 8 * a]
+            p = 0.0
+            for i in range(8):                     # Horner, highest power first (uav_trajectory.py:22-28)
+                p = p * tl + c[7 - i]
+            d = [(i + 1) * c[i + 1] for i in range(7)]
+            v = 0.0
+            for i in range(7):
+                v = v * tl + d[6 - i]
+            x[k, a] = p
+            x[k, 7 + a] = v
+    x[:, 0:3] = np.round(x[:, 0:3], 6)
+    x[:, 7:10] = np.round(x[:, 7:10], 6)
+    return x, np.round(ts, 6)

@@ -193,7 +193,36 @@ def make_circle_vectors():
     print("wrote circle_vectors.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_poly_vectors():
+    """Sampled references of random piecewise polynomials through the reference's own evaluator
+    (uav_trajectory.Trajectory.loadcsv / eval) and TrajectoryGenerator.save_evals_csv / load_trajectory."""
+    import tempfile
+    sys.path.insert(0, os.path.join(REF, "src", "trajectory_generation"))
+    import TrajectoryGenerator as TG
+    import uav_trajectory
+    rng = np.random.default_rng(11)
+    d = tempfile.mkdtemp()
+    g = TG.TrajectoryGenerator.__new__(TG.TrajectoryGenerator)
+    g.sampled_trajectory_filename = os.path.join(d, "s.csv")
+    out = {}
+    for case, (npieces, dt) in enumerate([(3, 0.01), (5, 0.05), (1, 0.02)]):
+        pieces = np.zeros((npieces, 33))
+        pieces[:, 0] = np.round(rng.uniform(0.4, 1.7, npieces), 6)
+        pieces[:, 1:] = np.round(rng.normal(0, 1.0, (npieces, 32)) * (0.5 ** np.tile(np.arange(8), 4)), 6)
+        f = os.path.join(d, f"p{case}.csv")
+        np.savetxt(f, pieces, fmt="%.6f", delimiter=",", header="duration," + ",".join(f"c{i}" for i in range(32)))
+        tr = uav_trajectory.Trajectory()
+        tr.loadcsv(f)
+        g.save_evals_csv(tr, g.sampled_trajectory_filename, dt=dt)
+        x, t = g.load_trajectory()
+        out[f"p{case}_pieces"] = pieces; out[f"p{case}_dt"] = dt; out[f"p{case}_x"] = x; out[f"p{case}_t"] = t
+    out["ncases"] = 3
+    np.savez_compressed(os.path.join(OUT, "poly_vectors.npz"), **out)
+    print("wrote poly_vectors.npz", {k: np.shape(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    make_poly_vectors()
     make_circle_vectors()
     make_logs()
     make_rgp_vectors()

@@ -110,3 +110,15 @@ def test_circle_references_match_reference_generator():
     assert x.shape == g["const_x"].shape and np.abs(x - g["const_x"]).max() <= 1.5e-6
     x, t = circle_trajectory("acc_dec", 10, 10, dt=0.01)
     assert x.shape == g["ad_x"].shape and np.abs(x - g["ad_x"]).max() <= 1.5e-6
+
+
+def test_polynomial_references_match_reference_sampler():
+    """Piecewise-polynomial references (the output format of the reference's min-snap generator) sampled by
+    trajectories.sample_polynomial_trajectory against vectors from the reference's own uav_trajectory evaluator +
+    TrajectoryGenerator.save_evals_csv / load_trajectory (tests/golden/make_golden.py: make_poly_vectors)."""
+    from mpc_quad_ros_amd.trajectories import sample_polynomial_trajectory
+    g = np.load(os.path.join(ROOT, "tests", "golden", "poly_vectors.npz"))
+    for c in range(int(g["ncases"])):
+        x, t = sample_polynomial_trajectory(g[f"p{c}_pieces"], float(g[f"p{c}_dt"]))
+        assert x.shape == g[f"p{c}_x"].shape
+        assert np.abs(x - g[f"p{c}_x"]).max() <= 1.5e-6 and np.abs(t - g[f"p{c}_t"]).max() < 1e-9
