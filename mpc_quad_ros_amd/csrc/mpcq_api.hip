@@ -454,12 +454,19 @@ struct EngineT : mpcq_engine {
     const int nev = (K + stride - 1) / stride;
     while ((int)kev.size() < 2 * nev) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
     HIP_TRY(hipEventRecord(ev0, stream));
+    // The plant update between two control periods rides at the head of the next step launch (MODE_PLANT_FIRST), where
+    // it overlaps that launch's global loads; only the update after the last period needs the plant kernel.
+    // MPCQ_SIM_SPLIT=1 restores one plant kernel per period.
+    static const bool split = getenv("MPCQ_SIM_SPLIT") != nullptr;
+    s2.run_x = d_xs; s2.run_steps = 1; s2.run_nsub = n_sub; s2.run_dt = sim_dt;
     for (int k = 0; k < K; ++k) {
       const bool timed_launch = k % stride == 0;
+      const int mode = mpcq::MODE_TRAJ | mpcq::MODE_POST | ((!split && k > 0) ? mpcq::MODE_PLANT_FIRST : 0);
       if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride)], stream));
-      hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+      hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mode);
       if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride) + 1], stream));
-      hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, sim_dt, B);
+      if (split || k == K - 1)
+        hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, sim_dt, B);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));

@@ -51,7 +51,10 @@ constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded 
 constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
 constexpr int SUBS = 4 * SUBW + 1;  // per-stage stride of the records (odd: lanes of different stages hit different banks)
 
-enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4 };   // MODE_RUN: free-running closed loop, DevState::run_* periods per launch
+enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4, MODE_PLANT_FIRST = 8 };
+// MODE_RUN: free-running closed loop, DevState::run_* periods per launch.  MODE_PLANT_FIRST: the launch starts by
+// advancing the plant state run_x with the previous launch's control (lockstep closed loop without a plant kernel
+// between two step launches: the integration overlaps the global loads of the load phase).
 
 // Diagnostic build only (-DMPCQ_PROFILE, libmpcq_prof.so): per-phase shader-cycle totals per instance.
 enum : int { PF_LOAD = 0, PF_SHOOT_X, PF_SHOOT_S, PF_FACTOR, PF_FWD, PF_BWD, PF_ADJ, PF_ROLL, PF_ELEM, PF_POST, PF_TOTAL, PF_N = 16 };
@@ -1681,6 +1684,18 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     }
   };
   load_block(0);
+  if (mode & MODE_PLANT_FIRST) {
+    if (tid == 0) {
+      double x[NX], u[NU];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) x[k] = st.run_x[(size_t)b * NX + k];
+#pragma unroll
+      for (int k = 0; k < NU; ++k) u[k] = st.w[(size_t)b * NU + k];
+      for (int sub = 0; sub < st.run_nsub; ++sub) plant_rk4(m, x, u, st.run_dt);
+#pragma unroll
+      for (int k = 0; k < NX; ++k) st.run_x[(size_t)b * NX + k] = x[k];
+    }
+  }
   const double xm = tid < NX ? st.x_meas[(size_t)b * NX + tid] : 0.0;
   if (gp) {   // mu -> LDS scratch (shooting records are not live yet); rows of Kx^-1 come straight from L2
     for (int i = tid; i < 3 * nb; i += 64) { S[L.sub + i] = gmu[i]; S[L.basis + i] = m.basis[i]; }
