@@ -120,3 +120,35 @@ def case_swarm_closed_loop(make_engine, B, N, nb, K, precision=0, seed=1, plant_
     se, so = e.get_tracking_stats(), o.get_tracking_stats()
     assert np.allclose(se[:4], so, rtol=1e-6 if precision == 0 else 1e-3, atol=1e-9)
     return worst
+
+
+def case_saturating_references(make_engine, B=3, K=40, precision=0):
+    """Teacher-forced run on deliberately infeasible references (fast lateral sinusoid + vertical steps): the thrust
+    saturates on large parts of the horizon and the working set changes by many inputs per step, so the warm
+    active-set attempt goes through many working sets (restarted factorisations, bulk pins / releases) and regularly
+    gives up to the interior-point fallback.  Returns (worst relative control deviation, histogram of pass counts)."""
+    N, nb = 20, 10
+    kw = dict(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb))
+    e, o = make_engine(EngineConfig(precision=precision, **kw)), OracleEngine(EngineConfig(**kw))
+    T = 60 + K * 5
+    traj = np.zeros((B, T, 13)); traj[:, :, 3] = 1.0
+    t = np.arange(T) * 0.01
+    for b in range(B):
+        A, w = 2.0 + b, 3.0 + 0.7 * b
+        traj[b, :, 0] = A * np.sin(w * t); traj[b, :, 7] = A * w * np.cos(w * t)
+        traj[b, :, 2] = 3.0 + 1.5 * np.sign(np.sin(2.0 * t + b))
+    lens = np.full(B, T, dtype=np.int32)
+    e.set_trajectories(traj, lens); o.set_trajectories(traj, lens)
+    x = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    worst, hist = 0.0, {}
+    for k in range(K):
+        w_e, _ = e.step(x)
+        w_o, _ = o.step(x)
+        assert (e.get_status() == 0).all(), (k, e.get_status())
+        for v in e.get_qp_iter():
+            hist[int(v)] = hist.get(int(v), 0) + 1
+        worst = max(worst, rel_err(w_e, w_o))
+        x = o.plant_control_period(x, w_o, 0.01, 5e-3)[0]
+        st = o.get_state()
+        e.set_state(X=st["X"], U=st["U"], mu=st["mu"], C=st["C"], x_pred_prev=st["x_pred_prev"], has_prev=st["has_prev"], idx=st["idx"])
+    return worst, hist

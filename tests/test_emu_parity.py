@@ -45,6 +45,13 @@ def test_emu_swarm_closed_loop_hummingbird():
     assert pc.case_swarm_closed_loop(make, B=3, N=10, nb=10, K=6) < 1e-7
 
 
+def test_emu_saturating_references_many_working_sets():
+    worst, hist = pc.case_saturating_references(make, B=2, K=22)
+    print("saturating references: worst", worst, "passes", dict(sorted(hist.items())))
+    assert worst < 1e-7
+    assert any(2 <= v < 1000 for v in hist) and any(v >= 1000 for v in hist)   # multi-pass warm attempts AND fallbacks were exercised
+
+
 def test_emu_lane_order_independent(monkeypatch):
     # a missing barrier would make results depend on the order lanes run within a phase
     import ctypes, shutil, tempfile

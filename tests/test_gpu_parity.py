@@ -217,3 +217,14 @@ def test_config2_full_size():
         out.append((x, w, e.get_tracking_stats()))
         e.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_saturating_references_many_working_sets(precision):
+    worst, hist = pc.case_saturating_references(make, B=16, K=60, precision=precision)
+    print("saturating references: worst", worst, "passes", dict(sorted(hist.items())))
+    # fp64 keeps its parity through dozens of working sets per step.  The fp32 QP is a fast mode for trackable
+    # references: on these infeasible ones (thrust saturated over most of the horizon, ill-conditioned working sets)
+    # it stays robust (every instance solves) but only to ~1e-2 -- outside the 1e-4 budget, and documented as such.
+    assert worst < (1e-7 if precision == 0 else 2e-2)
+    assert any(2 <= v < 1000 for v in hist)
