@@ -41,7 +41,7 @@ typedef enum mpcq_status {
 
 /* per-instance solver status, the acados return codes the reference discards (src/quad_opt.py:333) */
 #define MPCQ_SOLVE_OK 0
-#define MPCQ_SOLVE_NAN 1
+#define MPCQ_SOLVE_NAN 1          /* the QP step was not finite: the instance kept its previous iterate and control */
 #define MPCQ_SOLVE_MAXITER 2
 #define MPCQ_SOLVE_QP_FAILURE 4
 

@@ -1764,16 +1764,25 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   // ---- 2. QP
   int status = 0;
   const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b] > 0 PF_PASS);
-  // ---- 3. full step (iterate accumulated in double)
-  for (int it = tid; it < (N + 1) * NX; it += 64) {
-    const int i = it / NX, k = it - i * NX;
-    const double v = D[L.X + it] + (double)S[L.dx + i * VS + o2i(k)];
-    D[L.X + it] = v; gX[it] = v;
-  }
-  for (int i = tid; i < nv; i += 64) {
-    double v = D[L.U + i] + (double)S[L.z + i];
-    v = tmin(tmax(v, m.ulb[i & 3]), m.uub[i & 3]);   // the QP keeps du inside [lb, ub]; removes the rounding of TQ -> double
-    D[L.U + i] = v; gU[i] = v;
+  // ---- 3. full step (iterate accumulated in double).  A step that is not finite (a QP that broke down: only seen
+  //      with the fp32 QP on infeasible references) is not taken: the iterate and the control of the previous period
+  //      stay, the instance reports MPCQ_SOLVE_NAN and starts the next period from a sound iterate.
+  int unsound = 0;
+  for (int it = tid; it < (N + 1) * VS; it += 64) { const TQ v = S[L.dx + it]; if (!(tabs(v) < TQ(1e30))) unsound = 1; }
+  for (int i = tid; i < nv; i += 64) { const TQ v = S[L.z + i]; if (!(tabs(v) < TQ(1e30))) unsound = 1; }
+  unsound = wave_max(unsound);
+  if (unsound) status = 1;
+  else {
+    for (int it = tid; it < (N + 1) * NX; it += 64) {
+      const int i = it / NX, k = it - i * NX;
+      const double v = D[L.X + it] + (double)S[L.dx + i * VS + o2i(k)];
+      D[L.X + it] = v; gX[it] = v;
+    }
+    for (int i = tid; i < nv; i += 64) {
+      double v = D[L.U + i] + (double)S[L.z + i];
+      v = tmin(tmax(v, m.ulb[i & 3]), m.uub[i & 3]);   // the QP keeps du inside [lb, ub]; removes the rounding of TQ -> double
+      D[L.U + i] = v; gU[i] = v;
+    }
   }
   __syncthreads();
   // cost at the new iterate (get_cost)

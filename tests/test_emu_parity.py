@@ -46,7 +46,8 @@ def test_emu_swarm_closed_loop_hummingbird():
 
 
 def test_emu_saturating_references_many_working_sets():
-    worst, hist = pc.case_saturating_references(make, B=2, K=22)
+    worst, hist, failed = pc.case_saturating_references(make, B=2, K=22)
+    assert failed == 0
     print("saturating references: worst", worst, "passes", dict(sorted(hist.items())))
     assert worst < 1e-7
     assert any(2 <= v < 1000 for v in hist) and any(v >= 1000 for v in hist)   # multi-pass warm attempts AND fallbacks were exercised

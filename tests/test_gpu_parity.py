@@ -221,10 +221,12 @@ def test_config2_full_size():
 
 @pytest.mark.parametrize("precision", [0, 1])
 def test_saturating_references_many_working_sets(precision):
-    worst, hist = pc.case_saturating_references(make, B=16, K=60, precision=precision)
-    print("saturating references: worst", worst, "passes", dict(sorted(hist.items())))
+    worst, hist, failed = pc.case_saturating_references(make, B=16, K=60, precision=precision)
+    print("saturating references: worst", worst, "failed", failed, "passes", dict(sorted(hist.items())))
     # fp64 keeps its parity through dozens of working sets per step.  The fp32 QP is a fast mode for trackable
     # references: on these infeasible ones (thrust saturated over most of the horizon, ill-conditioned working sets)
-    # it stays robust (every instance solves) but only to ~1e-2 -- outside the 1e-4 budget, and documented as such.
+    # it only reaches ~1e-2 -- outside the 1e-4 budget, documented as such -- and an occasional solve breaks down: the
+    # instance then reports MPCQ_SOLVE_NAN and holds its previous iterate and control (at most a handful of 960 here).
     assert worst < (1e-7 if precision == 0 else 2e-2)
+    assert failed == 0 if precision == 0 else failed <= 10
     assert any(2 <= v < 1000 for v in hist)
