@@ -1764,6 +1764,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   // ---- 2. QP
   int status = 0;
   const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b] > 0 PF_PASS);
+  PF_START();
   // ---- 3. full step (iterate accumulated in double).  A step that is not finite (a QP that broke down: only seen
   //      with the fp32 QP on infeasible references) is not taken: the iterate and the control of the previous period
   //      stay, the instance reports MPCQ_SOLVE_NAN and starts the next period from a sound iterate.
@@ -1817,6 +1818,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   if (bad) status = 1;
   if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; }
   if (tid < NU) st.w[(size_t)b * NU + tid] = D[L.U + tid];
+  PF_STOP(PF_ELEM);
   PF_START();
   if (mode & MODE_POST) {
   // ---- 4. post: nominal prediction, cursor, drag estimate, RGP regress, statistics

@@ -13,7 +13,7 @@ from mpc_quad_ros_amd.engine import Engine  # noqa: E402
 from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace  # noqa: E402
 from mpc_quad_ros_amd.trajectories import swarm_trajectories  # noqa: E402
 
-NAMES = ["load", "shoot_x", "shoot_s", "factor", "fwd", "bwd", "adjoint", "rollout", "elem", "post", "total"]
+NAMES = ["load", "shoot_x", "shoot_s", "factor", "fwd", "bwd", "adjoint", "rollout", "update", "post", "total"]
 FINE = {11: "fwd: loads/shift", 12: "fwd: K Dx chain", 13: "fwd: broadcast", 14: "fwd: A Dx chain"}
 
 
