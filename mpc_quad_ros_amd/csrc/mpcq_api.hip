@@ -150,6 +150,7 @@ struct EngineT : mpcq_engine {
   void (*krun)(const mpcq::DevModel<T>, const mpcq::DevState<T>, const int) = nullptr;   // free-running variant (mpcq_sim_run)
   std::vector<double> hbufd;
   T *d_basis = nullptr, *d_Kxinv = nullptr, *d_Kx = nullptr;
+  double* h_pin = nullptr;   // pinned staging of the host-buffer step: [x_meas B*13 | w B*4 | x_pred B*13]
   double *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr, *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
   int* d_tlen = nullptr;
   std::vector<T> hbuf;
@@ -160,6 +161,7 @@ struct EngineT : mpcq_engine {
                     st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
+    if (h_pin) (void)hipHostFree(h_pin);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     for (hipEvent_t ev : kev) (void)hipEventDestroy(ev);
@@ -422,12 +424,20 @@ struct EngineT : mpcq_engine {
   }
   int step(const double* x_meas, double* w_out, double* x_pred_out) override {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_step needs mpcq_set_trajectories first");
-    int rc;
-    if ((rc = h2d(d_xin, x_meas, (size_t)B * 13))) return rc;
+    // host buffers go through one pinned staging block so that the three copies are truly asynchronous and the
+    // call synchronises once: H2D x_meas -> step kernel -> D2H w, x_pred
+    const size_t nx = (size_t)B * 13, nw = (size_t)B * 4;
+    if (!h_pin) HIP_TRY(hipHostMalloc((void**)&h_pin, (2 * nx + nw) * sizeof(double), hipHostMallocDefault));
+    std::memcpy(h_pin, x_meas, nx * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(d_xin, h_pin, nx * sizeof(double), hipMemcpyHostToDevice, stream));
     st.x_meas = d_xin;
+    int rc;
     if ((rc = launch_step(mpcq::MODE_TRAJ | mpcq::MODE_POST))) return rc;
-    if ((rc = d2h(w_out, st.w, (size_t)B * 4))) return rc;
-    if (x_pred_out && (rc = d2h(x_pred_out, st.xpred, (size_t)B * 13))) return rc;
+    HIP_TRY(hipMemcpyAsync(h_pin + nx, st.w, nw * sizeof(double), hipMemcpyDeviceToHost, stream));
+    if (x_pred_out) HIP_TRY(hipMemcpyAsync(h_pin + nx + nw, st.xpred, nx * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::memcpy(w_out, h_pin + nx, nw * sizeof(double));
+    if (x_pred_out) std::memcpy(x_pred_out, h_pin + nx + nw, nx * sizeof(double));
     return 0;
   }
   int step_device(const void* d_x, void* d_w) override {

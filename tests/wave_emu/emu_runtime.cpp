@@ -74,6 +74,8 @@ struct emuEvent { std::chrono::steady_clock::time_point t; };
 const char* hipGetErrorString(hipError_t) { return "emu"; }
 hipError_t hipGetDeviceCount(int* n) { *n = 8; return hipSuccess; }   // pretend an 8-GPU node so multi-rank tests can use LOCAL_RANK as the ordinal
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }

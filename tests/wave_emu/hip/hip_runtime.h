@@ -164,6 +164,9 @@ constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 const char* hipGetErrorString(hipError_t);
 hipError_t hipGetDeviceCount(int*);
 hipError_t hipSetDevice(int);
+#define hipHostMallocDefault 0
+hipError_t hipHostMalloc(void**, size_t, unsigned);
+hipError_t hipHostFree(void*);
 struct hipDeviceProp_t { int multiProcessorCount; };
 hipError_t hipGetDeviceProperties(hipDeviceProp_t*, int);
 hipError_t hipMalloc(void**, size_t);
