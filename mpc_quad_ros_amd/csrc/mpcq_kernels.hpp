@@ -1219,7 +1219,10 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
   bool refactor = true, settled = false;
   int nact = 1;   // pinned inputs in the working set
-  bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
+  // a bulk release that bounces straight back (the freed inputs violate and get pinned again) makes the next ones
+  // more selective: all wrong-signed multipliers -> those within 4x of the worst -> within 1.6x -> the worst only
+  int careful = 0;
+  bool released = false;
   int top = N - 1;   // highest stage whose working set changed since the last factorisation (N-1: factorise everything)
   bool keep_p = false;
   for (passes = 0; passes < max_passes; ++passes) {
@@ -1308,11 +1311,12 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
 #endif
       if (vmax <= tolm) { settled = true; break; }
       __syncthreads();
+      const TQ rel_thr = careful == 0 ? TQ(0) : (careful == 1 ? TQ(0.25) * vmax : (careful == 2 ? TQ(0.625) * vmax : vmax));
       int hi = -1;
       for (int i = tid; i < nv; i += 64) {
         const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
         const TQ v = a < 0 ? -g : g;
-        if (a != TQ(0) && (careful ? v >= vmax : v > tolm)) { S[L.act + i] = 0; hi = i >> 2; }   // release wrong-signed multipliers (all, or the worst)
+        if (a != TQ(0) && v > tolm && v >= rel_thr) { S[L.act + i] = 0; hi = i >> 2; }   // release wrong-signed multipliers
       }
       top = tmax(top, wave_max(hi));
       refactor = true;
@@ -1349,7 +1353,10 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) printf("     pass %d aff %d alpha %.6e nblk %d\n", passes, (int)aff, (double)alpha, nblk);
 #endif
-    if (nblk > 0) { refactor = true; if (released) careful = true; }
+    // a bulk release that bounces back wholesale with most of the inputs saturated: far from the optimal working set,
+    // the interior point gets there faster
+    if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) return false;
+    if (nblk > 0) { refactor = true; if (released && careful < 3) careful += 1; }
     released = false;
     __syncthreads();
   }
@@ -1381,7 +1388,10 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
   bool refactor = true, settled = false, full = false;
   int nact = 1;   // pinned inputs in the working set (unknown before the first count)
-  bool careful = false, released = false;   // bulk releases that bounce straight back switch to one-at-a-time
+  // a bulk release that bounces straight back (the freed inputs violate and get pinned again) makes the next ones
+  // more selective: all wrong-signed multipliers -> those within 4x of the worst -> within 1.6x -> the worst only
+  int careful = 0;
+  bool released = false;
   bool dx_done = false;   // the forward sweep already produced the state trajectory (affine pass)
   bool incremental = false;   // the state trajectory has been updated by increments since it was last computed from z
   TQ gF_prev = TQ(1e30);
@@ -1451,10 +1461,11 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
     if (full) {
       // the point minimises the QP on the working set: multipliers are meaningful here only
       if (vmax > tolm) {
+        const TQ rel_thr = careful == 0 ? TQ(0) : (careful == 1 ? TQ(0.25) * vmax : (careful == 2 ? TQ(0.625) * vmax : vmax));
         for (int i = tid; i < nv; i += 64) {
           const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
           const TQ v = a < 0 ? -g : g;
-          if (a != TQ(0) && (careful ? v >= vmax : v > tolm)) S[L.act + i] = 0;   // release wrong-signed multipliers (all, or the worst)
+          if (a != TQ(0) && v > tolm && v >= rel_thr) S[L.act + i] = 0;   // release wrong-signed multipliers
         }
         refactor = true;
         released = true;
@@ -1501,7 +1512,8 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
     if (tid == 0) printf("     alpha %.6e nblk %d\n", (double)alpha, nblk);
 #endif
     full = nblk == 0;
-    if (nblk > 0) { refactor = true; if (released) careful = true; }
+    if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) return false;   // wholesale bounce in a saturated regime: leave it to the interior point
+    if (nblk > 0) { refactor = true; if (released && careful < 3) careful += 1; }
     released = false;
     __syncthreads();
   }
