@@ -250,6 +250,10 @@ def main():
                 t = json.load(f)
             out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
             out["roofline"]["traffic_source"] = t.get("source")
+            if args.precision == "f64":
+                out["roofline"]["traffic_note"] = ("fp64 keeps the per-stage records (38.6 KB per instance) in global memory, streamed through L2, so "
+                                                   "that 4 instead of 2 instances fit a CU: ~8x the algorithmic bytes at 0.15 ms per launch; "
+                                                   "the all-LDS placement (MPCQ_STAGE_MEM=lds) moves 15 MB and takes 0.27 ms")
         if world == 1 and not args.no_alt:
             # Same K periods as ONE launch in which every quadrotor runs through its periods without waiting for the
             # slowest member of the batch (mpcq_sim_run): the lockstep figure above is what a controller fed by live
