@@ -70,6 +70,7 @@ typedef struct mpcq_config {
   int32_t precision;     /* MPCQ_PRECISION_* : arithmetic type of the device path */
   int32_t qp_max_iter;   /* 0 = default */
   int32_t reserved;
+  double finish_radius;  /* EPSILON_TRAJECTORY_FINISHED [m], src/mpc_controller_node.py:118; 0 = default 1.0 */
 } mpcq_config;
 
 typedef struct mpcq_engine mpcq_engine;
@@ -97,6 +98,7 @@ int mpcq_set_params(mpcq_engine* e, const double* mu);
 /* ---- quad_optimizer.run_optimization (src/quad_opt.py:321-350): pin x0, ONE SQP-RTI iteration
  * on the persisted iterate, using the stored reference and parameters.  x0 [B, 13]. */
 int mpcq_solve(mpcq_engine* e, const double* x0);
+/* .get(stage,·): one strided device-to-host copy of the B rows of that stage per call */
 int mpcq_get_x(mpcq_engine* e, int32_t stage, double* out);      /* .get(stage,'x') -> [B,13] */
 int mpcq_get_u(mpcq_engine* e, int32_t stage, double* out);      /* .get(stage,'u') -> [B,4]  */
 int mpcq_get_cost(mpcq_engine* e, double* out);                  /* .get_cost()     -> [B]    */
@@ -120,11 +122,26 @@ int mpcq_get_rgp(mpcq_engine* e, double* mu /*[B,3,nb] or NULL*/, double* C /*[B
  * idx_traj++ -> compute_a_drag -> RGP regress -> params.  x_meas [B,13] -> w_out [B,4];
  * x_pred_out [B,13] may be NULL. */
 int mpcq_step(mpcq_engine* e, const double* x_meas, double* w_out, double* x_pred_out);
-/* Same with device-resident buffers in the engine's compute precision (float for F32, double for
- * F64): no host traffic, no synchronisation; ordered on the engine's stream. */
-int mpcq_step_device_async(mpcq_engine* e, const void* d_x_meas, void* d_w_out);
+/* Same with device-resident buffers: d_x_meas [B,13] and d_w_out [B,4] (NULL: engine-internal) are
+ * float64 device pointers in EVERY precision (the measurement and the iterate are always double; the
+ * precision only selects the arithmetic of the QP).  No host traffic, no synchronisation; ordered on
+ * the engine's stream. */
+int mpcq_step_device_async(mpcq_engine* e, const double* d_x_meas, double* d_w_out);
 int mpcq_synchronize(mpcq_engine* e);
 void* mpcq_stream(mpcq_engine* e);   /* hipStream_t the engine launches on */
+
+/* ---- command mapping of publish_control_gazebo (src/mpc_controller_node.py:600-612) for the last
+ * step / solve: rotor_thrusts [B,4] = w * max_thrust / mass, collective_thrust [B] = sum(w) * max_thrust
+ * / mass, bodyrates [B,3] = x_opt[1, 10:13] (src/mpc_controller_node.py:292).  Any pointer may be NULL. */
+int mpcq_get_command(mpcq_engine* e, double* rotor_thrusts, double* collective_thrust, double* bodyrates);
+/* ---- trajectory finished (src/mpc_controller_node.py:374): per instance 1 once a fused step found
+ * idx_traj + 1 == len(trajectory) (after its idx_traj += 1) with the quadrotor closer than
+ * finish_radius to the first row of that step's reference chunk; sticky until mpcq_set_trajectories
+ * or mpcq_reset.  out [B]. */
+int mpcq_get_finished(mpcq_engine* e, int32_t* out);
+/* get_reference_chunk (src/utils/utils.py:897-931) at the current cursor, evaluated on the device
+ * with the row selection of the fused step.  out [B, N, 13]. */
+int mpcq_get_reference_chunk(mpcq_engine* e, double* out);
 
 /* ---- closed-loop harness on the device: Quadrotor3D.update with drag
  * (src/quad.py:166-190,234-277,329-357) applied n_sub times with step sim_dt to the engine's
@@ -137,11 +154,24 @@ int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt);
  * quadrotor).  Same arithmetic, same results as mpcq_sim_steps; the per-period outputs readable afterwards
  * (mpcq_get_*, mpcq_sim_get_state) are those of the last period. */
 int mpcq_sim_run(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt);
+/* The reference's plant loop between two solves (src/execute_trajectory.py:232-243):
+ * `while control_time < optimization_dt: quad.update(w, simulation_dt); control_time += simulation_dt`.
+ * mpcq_plant_substeps reproduces its iteration count with the same double accumulation (20 / 11 / 4
+ * substeps for control_dt = 0.1 / 0.05 / 0.02 at sim_dt = 5e-3); negative on bad arguments.
+ * mpcq_sim_plant_period advances the plant state by that loop with control w [B,4] (NULL: the last
+ * control of the engine); mpcq_sim_control_periods = K x {fused step -> that loop}. */
+int mpcq_plant_substeps(double control_dt, double sim_dt);
+int mpcq_sim_plant_period(mpcq_engine* e, const double* w, double control_dt, double sim_dt, int32_t* n_sub /*out, may be NULL*/);
+int mpcq_sim_control_periods(mpcq_engine* e, int32_t K, double control_dt, double sim_dt, int32_t* n_sub /*out, may be NULL*/);
 int mpcq_sim_get_state(mpcq_engine* e, double* x /*[B,13]*/, double* w /*[B,4] or NULL*/);
 /* HIP-event time of the step-kernel launches of the last mpcq_sim_steps / mpcq_sim_run call (events recorded on
  * the engine's stream around every 4th launch, MPCQ_KEV_STRIDE=1 for every launch): total seconds of the timed
  * launches and their number. */
 int mpcq_get_kernel_time(mpcq_engine* e, double* seconds, int32_t* launches);
+int mpcq_get_kernel_time_minmax(mpcq_engine* e, double* fastest_s, double* slowest_s);   /* of the same timed launches */
+/* diagnostic build only (libmpcq_prof.so, -DMPCQ_PROFILE): per-instance shader-cycle totals per phase of
+ * the last step, out [B][16]; MPCQ_ERR_STATE in the product build. */
+int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out);
 
 /* ---- tracking statistic (src/Visualiser.py:787-789,809-811,918), summed over this engine's
  * instances since the last reset: out[0]=sum |e_pos|^2, out[1]=sum |e_vel|^2, out[2]=steps,
@@ -162,6 +192,12 @@ int mpcq_get_state(mpcq_engine* e, double* X, double* U, double* mu, double* C, 
                    int32_t* has_prev, int32_t* idx);
 int mpcq_set_state(mpcq_engine* e, const double* X, const double* U, const double* mu, const double* C,
                    const double* x_pred_prev, const int32_t* has_prev, const int32_t* idx);
+
+/* The rest of the resumable state: warm-start flag / pass count of the last solve qp_iter [B], the
+ * tracking accumulators stats [B,4] (sum |e_pos|^2, sum |e_vel|^2, steps, max |e_pos|^2) and the
+ * finished flags [B].  With mpcq_get_state + mpcq_sim_get_state a restored engine continues bit for bit. */
+int mpcq_get_solver_state(mpcq_engine* e, int32_t* qp_iter, double* stats, int32_t* finished);
+int mpcq_set_solver_state(mpcq_engine* e, const int32_t* qp_iter, const double* stats, const int32_t* finished);
 
 #ifdef __cplusplus
 }

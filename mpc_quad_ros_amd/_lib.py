@@ -38,17 +38,27 @@ SYMBOLS = [
     ("mpcq_step_device_async", ctypes.c_int, [_vp, _vp, _vp]),
     ("mpcq_synchronize", ctypes.c_int, [_vp]),
     ("mpcq_stream", _vp, [_vp]),
+    ("mpcq_get_command", ctypes.c_int, [_vp, _dp, _dp, _dp]),
+    ("mpcq_get_finished", ctypes.c_int, [_vp, _ip]),
+    ("mpcq_get_reference_chunk", ctypes.c_int, [_vp, _dp]),
+    ("mpcq_plant_substeps", ctypes.c_int, [ctypes.c_double, ctypes.c_double]),
+    ("mpcq_sim_plant_period", ctypes.c_int, [_vp, _dp, ctypes.c_double, ctypes.c_double, _ip]),
+    ("mpcq_sim_control_periods", ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, _ip]),
     ("mpcq_sim_reset", ctypes.c_int, [_vp, _dp]),
     ("mpcq_sim_steps", ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
     ("mpcq_sim_run", ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]),
     ("mpcq_sim_get_state", ctypes.c_int, [_vp, _dp, _dp]),
     ("mpcq_get_kernel_time", ctypes.c_int, [_vp, _dp, _ip]),
+    ("mpcq_get_kernel_time_minmax", ctypes.c_int, [_vp, _dp, _dp]),
+    ("mpcq_debug_profile", ctypes.c_int, [_vp, _vp]),
     ("mpcq_get_tracking_stats", ctypes.c_int, [_vp, _dp]),
     ("mpcq_comm_unique_id", ctypes.c_int, [_vp]),
     ("mpcq_comm_init", ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp]),
     ("mpcq_allreduce_tracking_stats", ctypes.c_int, [_vp, _dp]),
     ("mpcq_get_state", ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
     ("mpcq_set_state", ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
+    ("mpcq_get_solver_state", ctypes.c_int, [_vp, _ip, _dp, _ip]),
+    ("mpcq_set_solver_state", ctypes.c_int, [_vp, _ip, _dp, _ip]),
 ]
 
 

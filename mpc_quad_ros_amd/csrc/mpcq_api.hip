@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,17 @@ int rccl_load() {
 }
 constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_MAX = 2;
 
+// Every entry point runs with the engine's device current and restores the caller's afterwards (several engines on
+// different devices in one process, calls from other host threads).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 // SPD inverse through Cholesky (K_x = K(X,X) + sn^2 I; np.linalg.inv in the reference, src/gp/RGP.py:157)
 bool spd_inverse(const std::vector<double>& A, int n, std::vector<double>& Ai) {
   std::vector<double> G(A);
@@ -111,7 +123,7 @@ struct mpcq_engine {
   int nranks = 1;
   double* d_stats5 = nullptr;
   std::vector<hipEvent_t> kev;   // per-launch event pairs of the last sim_steps call
-  double ktime = 0;
+  double ktime = 0, kmin = 0, kmax = 0;   // HIP-event time of the timed step-kernel launches: total, fastest, slowest
   int klaunches = 0;
   virtual int init() = 0;
   virtual int reset() = 0;
@@ -127,13 +139,19 @@ struct mpcq_engine {
   virtual int regress(const double*, const double*) = 0;
   virtual int get_rgp(double*, double*) = 0;
   virtual int step(const double*, double*, double*) = 0;
-  virtual int step_device(const void*, void*) = 0;
+  virtual int step_device(const double*, double*) = 0;
   virtual int sim_reset(const double*) = 0;
   virtual int sim_steps(int, int, double) = 0;
   virtual int sim_run(int, int, double) = 0;
   virtual int sim_get(double*, double*) = 0;
   virtual int stats(double*) = 0;
   virtual int get_prof(unsigned long long*) = 0;
+  virtual int get_command(double*, double*, double*) = 0;
+  virtual int get_finished(int32_t*) = 0;
+  virtual int get_chunk(double*) = 0;
+  virtual int sim_plant(const double*, int, double) = 0;
+  virtual int get_solver_state(int32_t*, double*, int32_t*) = 0;
+  virtual int set_solver_state(const int32_t*, const double*, const int32_t*) = 0;
   virtual int get_state(double*, double*, double*, double*, double*, int32_t*, int32_t*) = 0;
   virtual int set_state(const double*, const double*, const double*, const double*, const double*, const int32_t*, const int32_t*) = 0;
 };
@@ -153,11 +171,14 @@ struct EngineT : mpcq_engine {
   double* h_pin = nullptr;   // pinned staging of the host-buffer step: [x_meas B*13 | w B*4 | x_pred B*13]
   double *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr, *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
   int* d_tlen = nullptr;
+  double* d_cmd = nullptr;   // [B*8] rotor thrusts, collective thrust, body rates (mpcq_get_command); also the chunk read-back
+  size_t cmd_elems = 0;
   std::vector<T> hbuf;
   std::vector<double> Kx;
 
   ~EngineT() override {
-    void* ptrs[] = {st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
+    DeviceGuard guard(cfg.device);
+    void* ptrs[] = {st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
                     st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -220,6 +241,7 @@ struct EngineT : mpcq_engine {
     if (const char* t = getenv("MPCQ_WARM_MAX")) m.warm_max = atoi(t);
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;
     m.h = c.T / c.N; m.dt_pred = c.dt_pred;
+    m.finish_r = c.finish_radius > 0 ? c.finish_radius : 1.0;
     m.mass = c.mass; m.tmax = c.max_thrust; m.g = c.g; m.aero_drag = c.aero_drag;
     for (int i = 0; i < 3; ++i) { m.J[i] = c.J[i]; m.iJ[i] = 1.0 / c.J[i]; m.rotor_drag[i] = c.rotor_drag[i]; }
     m.imass = 1.0 / c.mass;
@@ -272,6 +294,7 @@ struct EngineT : mpcq_engine {
     if ((rc = dalloc(st.idx, Bz))) return rc;
     if ((rc = dalloc(st.status, Bz))) return rc;
     if ((rc = dalloc(st.qp_iter, Bz))) return rc;
+    if ((rc = dalloc(st.finished, Bz))) return rc;
     if ((rc = dalloc(d_tlen, Bz))) return rc;
     if ((rc = dalloc(d_xin, Bz * 13))) return rc;
     if ((rc = dalloc(d_uin, Bz * 4))) return rc;
@@ -325,6 +348,7 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipMemsetAsync(st.idx, 0, Bz * sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(st.status, 0, Bz * sizeof(int), stream));
     HIP_TRY(hipMemsetAsync(st.qp_iter, 0, Bz * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(st.finished, 0, Bz * sizeof(int), stream));
     if (nb) {  // C_0 = K_x for every instance and axis
       std::vector<T> h((size_t)B * 3 * nb * nb);
       for (size_t b = 0; b < Bz; ++b)
@@ -347,6 +371,7 @@ struct EngineT : mpcq_engine {
     if ((rc = h2d(d_traj, traj, (size_t)B * Tmax * 13))) return rc;
     HIP_TRY(hipMemcpyAsync(d_tlen, len, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemsetAsync(st.idx, 0, (size_t)B * sizeof(int), stream));
+    HIP_TRY(hipMemsetAsync(st.finished, 0, (size_t)B * sizeof(int), stream));
     HIP_TRY(hipStreamSynchronize(stream));
     st.traj = d_traj;
     have_traj = true;
@@ -377,18 +402,17 @@ struct EngineT : mpcq_engine {
   }
   int get_x(int stage, double* out) override {
     if (stage < 0 || stage > N) return fail(MPCQ_ERR_INVALID, "stage out of range");
-    std::vector<double> all((size_t)B * (N + 1) * 13);
-    int rc;
-    if ((rc = d2h(all.data(), st.X, all.size()))) return rc;
-    for (int b = 0; b < B; ++b) std::memcpy(out + (size_t)b * 13, &all[((size_t)b * (N + 1) + stage) * 13], 13 * sizeof(double));
+    // one strided copy of the B rows of this stage (a reference-shaped `for i: get(i,'x')` loop stays O(N B))
+    HIP_TRY(hipMemcpy2DAsync(out, 13 * sizeof(double), st.X + (size_t)stage * 13, (size_t)(N + 1) * 13 * sizeof(double), 13 * sizeof(double), B,
+                             hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
   int get_u(int stage, double* out) override {
     if (stage < 0 || stage >= N) return fail(MPCQ_ERR_INVALID, "stage out of range");
-    std::vector<double> all((size_t)B * N * 4);
-    int rc;
-    if ((rc = d2h(all.data(), st.U, all.size()))) return rc;
-    for (int b = 0; b < B; ++b) std::memcpy(out + (size_t)b * 4, &all[((size_t)b * N + stage) * 4], 4 * sizeof(double));
+    HIP_TRY(hipMemcpy2DAsync(out, 4 * sizeof(double), st.U + (size_t)stage * 4, (size_t)N * 4 * sizeof(double), 4 * sizeof(double), B,
+                             hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
   int get_cost(double* out) override { return d2h(out, st.cost, B); }
@@ -440,11 +464,11 @@ struct EngineT : mpcq_engine {
     if (x_pred_out) std::memcpy(x_pred_out, h_pin + nx + nw, nx * sizeof(double));
     return 0;
   }
-  int step_device(const void* d_x, void* d_w) override {
+  int step_device(const double* d_x, double* d_w) override {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_step_device_async needs mpcq_set_trajectories first");
-    mpcq::DevState<T> s2 = st;
-    s2.x_meas = (const double*)d_x;
-    if (d_w) s2.w = (double*)d_w;
+    mpcq::DevState<T> s2 = st;   // measurement and control are float64 in every precision (DevState::x_meas / w)
+    s2.x_meas = d_x;
+    if (d_w) s2.w = d_w;
     HIP_TRY(hipEventRecord(ev0, stream));
     hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
     HIP_TRY(hipGetLastError());
@@ -459,7 +483,7 @@ struct EngineT : mpcq_engine {
     s2.x_meas = d_xs;
     // HIP events around every `stride`-th step-kernel launch (an event pair costs a few microseconds of dispatch
     // overlap, so only a sample of the launches carries one; MPCQ_KEV_STRIDE=1 times every launch)
-    int stride = 4;
+    int stride = K <= 50 ? 1 : 4;   // short runs: every launch
     if (const char* t = getenv("MPCQ_KEV_STRIDE")) stride = atoi(t) > 0 ? atoi(t) : 1;
     const int nev = (K + stride - 1) / stride;
     while ((int)kev.size() < 2 * nev) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
@@ -482,13 +506,15 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
     HIP_TRY(hipStreamSynchronize(stream));
-    ktime = 0;
+    ktime = 0; kmin = 1e30; kmax = 0;
     klaunches = nev;
     for (int k = 0; k < nev; ++k) {
       float ms = 0;
       HIP_TRY(hipEventElapsedTime(&ms, kev[2 * k], kev[2 * k + 1]));
       ktime += ms * 1e-3;
+      kmin = std::min(kmin, (double)ms * 1e-3); kmax = std::max(kmax, (double)ms * 1e-3);
     }
+    if (!nev) kmin = 0;
     return 0;
   }
   int sim_run(int K, int n_sub, double sim_dt) override {
@@ -508,7 +534,7 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipStreamSynchronize(stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, kev[0], kev[1]));
-    ktime = ms * 1e-3;
+    ktime = kmin = kmax = ms * 1e-3;
     klaunches = 1;
     return 0;
   }
@@ -525,6 +551,59 @@ struct EngineT : mpcq_engine {
       HIP_TRY(hipMemcpyAsync(out5, d_stats5, 5 * sizeof(double), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
     }
+    return 0;
+  }
+  int cmd_buf(size_t n) {
+    if (cmd_elems >= n) return 0;
+    if (d_cmd) { (void)hipFree(d_cmd); d_cmd = nullptr; cmd_elems = 0; }
+    HIP_TRY(hipMalloc((void**)&d_cmd, n * sizeof(double)));
+    cmd_elems = n;
+    return 0;
+  }
+  int get_command(double* rotor, double* coll, double* rates) override {
+    int rc;
+    if ((rc = cmd_buf((size_t)B * 8))) return rc;
+    hipLaunchKernelGGL(mpcq::command_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, st.w, st.X, d_cmd, d_cmd + (size_t)B * 4, d_cmd + (size_t)B * 5, B);
+    HIP_TRY(hipGetLastError());
+    if (rotor && (rc = d2h(rotor, d_cmd, (size_t)B * 4))) return rc;
+    if (coll && (rc = d2h(coll, d_cmd + (size_t)B * 4, (size_t)B))) return rc;
+    if (rates && (rc = d2h(rates, d_cmd + (size_t)B * 5, (size_t)B * 3))) return rc;
+    return 0;
+  }
+  int get_finished(int32_t* out) override {
+    HIP_TRY(hipMemcpyAsync(out, st.finished, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int get_chunk(double* out) override {
+    if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_get_reference_chunk needs mpcq_set_trajectories first");
+    int rc;
+    if ((rc = cmd_buf((size_t)B * N * 13))) return rc;
+    hipLaunchKernelGGL(mpcq::chunk_kernel<T>, dim3(B), dim3(64), 0, stream, m, st.traj, st.tlen, st.idx, d_cmd);
+    HIP_TRY(hipGetLastError());
+    return d2h(out, d_cmd, (size_t)B * N * 13);
+  }
+  int sim_plant(const double* w, int n_sub, double sim_dt) override {
+    int rc;
+    if (w && (rc = h2d(st.w, w, (size_t)B * 4))) return rc;
+    hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, sim_dt, B);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int get_solver_state(int32_t* qp_iter, double* stats4, int32_t* finished) override {
+    int rc;
+    if (qp_iter && (rc = get_int(1, qp_iter))) return rc;
+    if (stats4 && (rc = d2h(stats4, st.stats, (size_t)B * 4))) return rc;
+    if (finished && (rc = get_finished(finished))) return rc;
+    return 0;
+  }
+  int set_solver_state(const int32_t* qp_iter, const double* stats4, const int32_t* finished) override {
+    int rc;
+    if (qp_iter) HIP_TRY(hipMemcpyAsync(st.qp_iter, qp_iter, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (finished) HIP_TRY(hipMemcpyAsync(st.finished, finished, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (stats4 && (rc = h2d(st.stats, stats4, (size_t)B * 4))) return rc;
     return 0;
   }
   int get_prof(unsigned long long* out) override {
@@ -569,7 +648,7 @@ struct EngineT : mpcq_engine {
 extern "C" {
 
 const char* mpcq_last_error(void) { return g_err.c_str(); }
-const char* mpcq_version(void) { return "mpcq 0.1 (gfx950)"; }
+const char* mpcq_version(void) { return "mpcq 0.2 (gfx950)"; }
 
 int mpcq_create(const mpcq_config* c, mpcq_engine** out) {
   if (!c || !out) return fail(MPCQ_ERR_INVALID, "null argument");
@@ -582,10 +661,12 @@ int mpcq_create(const mpcq_config* c, mpcq_engine** out) {
     if (!(c->u_ub[i] > c->u_lb[i])) return fail(MPCQ_ERR_INVALID, "u_ub must exceed u_lb");
   for (int i = 13; i < 17; ++i)
     if (!(c->W[i] > 0)) return fail(MPCQ_ERR_INVALID, "input weights must be positive (strictly convex QP)");
+  if (c->finish_radius < 0) return fail(MPCQ_ERR_INVALID, "finish_radius must be >= 0 (0 = default 1 m)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(MPCQ_ERR_DEVICE, "no HIP device: libmpcq has no CPU path (the CPU restatement lives in oracle/ for tests only)");
   if (c->device < 0 || c->device >= ndev) return fail(MPCQ_ERR_INVALID, "device ordinal out of range");
+  DeviceGuard guard(c->device);
   mpcq_engine* e = nullptr;
   if (c->precision == MPCQ_PRECISION_F64) e = new EngineT<double>();
   else if (c->precision == MPCQ_PRECISION_F32) e = new EngineT<float>();
@@ -600,19 +681,20 @@ int mpcq_create(const mpcq_config* c, mpcq_engine** out) {
   return 0;
 }
 int mpcq_destroy(mpcq_engine* e) { delete e; return 0; }
-#define CHK(e) if (!(e)) return fail(MPCQ_ERR_INVALID, "null engine")
-int mpcq_reset(mpcq_engine* e) { CHK(e); return e->reset(); }
-int mpcq_set_trajectories(mpcq_engine* e, const double* t, const int32_t* len, int32_t Tmax) { CHK(e); if (!t || !len) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_trajectories(t, len, Tmax); }
-int mpcq_set_reference(mpcq_engine* e, const double* y, const double* yN) { CHK(e); if (!y || !yN) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_reference(y, yN); }
-int mpcq_set_params(mpcq_engine* e, const double* mu) { CHK(e); if (!mu && e->nb) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_params(mu); }
-int mpcq_solve(mpcq_engine* e, const double* x0) { CHK(e); if (!x0) return fail(MPCQ_ERR_INVALID, "x_init has to be set before running the optimization"); return e->solve(x0); }
-int mpcq_get_x(mpcq_engine* e, int32_t s, double* o) { CHK(e); return e->get_x(s, o); }
-int mpcq_get_u(mpcq_engine* e, int32_t s, double* o) { CHK(e); return e->get_u(s, o); }
-int mpcq_get_cost(mpcq_engine* e, double* o) { CHK(e); return e->get_cost(o); }
-int mpcq_get_status(mpcq_engine* e, int32_t* o) { CHK(e); return e->get_int(0, o); }
-int mpcq_get_qp_iter(mpcq_engine* e, int32_t* o) { CHK(e); return e->get_int(1, o); }
+// null check + the engine's device made current for the duration of the call
+#define ENTER(e) if (!(e)) return fail(MPCQ_ERR_INVALID, "null engine"); DeviceGuard guard_((e)->cfg.device)
+int mpcq_reset(mpcq_engine* e) { ENTER(e); return e->reset(); }
+int mpcq_set_trajectories(mpcq_engine* e, const double* t, const int32_t* len, int32_t Tmax) { ENTER(e); if (!t || !len) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_trajectories(t, len, Tmax); }
+int mpcq_set_reference(mpcq_engine* e, const double* y, const double* yN) { ENTER(e); if (!y || !yN) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_reference(y, yN); }
+int mpcq_set_params(mpcq_engine* e, const double* mu) { ENTER(e); if (!mu && e->nb) return fail(MPCQ_ERR_INVALID, "null argument"); return e->set_params(mu); }
+int mpcq_solve(mpcq_engine* e, const double* x0) { ENTER(e); if (!x0) return fail(MPCQ_ERR_INVALID, "x_init has to be set before running the optimization"); return e->solve(x0); }
+int mpcq_get_x(mpcq_engine* e, int32_t s, double* o) { ENTER(e); return e->get_x(s, o); }
+int mpcq_get_u(mpcq_engine* e, int32_t s, double* o) { ENTER(e); return e->get_u(s, o); }
+int mpcq_get_cost(mpcq_engine* e, double* o) { ENTER(e); return e->get_cost(o); }
+int mpcq_get_status(mpcq_engine* e, int32_t* o) { ENTER(e); return e->get_int(0, o); }
+int mpcq_get_qp_iter(mpcq_engine* e, int32_t* o) { ENTER(e); return e->get_int(1, o); }
 int mpcq_get_stats(mpcq_engine* e, double* t) {
-  CHK(e);
+  ENTER(e);
   if (e->timed) {
     float ms = 0;
     if (hipEventSynchronize(e->ev1) == hipSuccess && hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) e->last_time = ms * 1e-3;
@@ -620,21 +702,48 @@ int mpcq_get_stats(mpcq_engine* e, double* t) {
   if (t) *t = e->last_time;
   return 0;
 }
-int mpcq_predict_nominal(mpcq_engine* e, const double* x, const double* u, double dt, double* o) { CHK(e); return e->predict(x, u, dt, o); }
-int mpcq_rgp_regress(mpcq_engine* e, const double* vb, const double* ad) { CHK(e); return e->regress(vb, ad); }
-int mpcq_get_rgp(mpcq_engine* e, double* mu, double* C) { CHK(e); return e->get_rgp(mu, C); }
-int mpcq_step(mpcq_engine* e, const double* x, double* w, double* xp) { CHK(e); if (!x || !w) return fail(MPCQ_ERR_INVALID, "null argument"); return e->step(x, w, xp); }
-int mpcq_step_device_async(mpcq_engine* e, const void* dx, void* dw) { CHK(e); if (!dx) return fail(MPCQ_ERR_INVALID, "null argument"); return e->step_device(dx, dw); }
-int mpcq_synchronize(mpcq_engine* e) { CHK(e); HIP_TRY(hipStreamSynchronize(e->stream)); return 0; }
+int mpcq_predict_nominal(mpcq_engine* e, const double* x, const double* u, double dt, double* o) { ENTER(e); return e->predict(x, u, dt, o); }
+int mpcq_rgp_regress(mpcq_engine* e, const double* vb, const double* ad) { ENTER(e); return e->regress(vb, ad); }
+int mpcq_get_rgp(mpcq_engine* e, double* mu, double* C) { ENTER(e); return e->get_rgp(mu, C); }
+int mpcq_step(mpcq_engine* e, const double* x, double* w, double* xp) { ENTER(e); if (!x || !w) return fail(MPCQ_ERR_INVALID, "null argument"); return e->step(x, w, xp); }
+int mpcq_step_device_async(mpcq_engine* e, const double* dx, double* dw) { ENTER(e); if (!dx) return fail(MPCQ_ERR_INVALID, "null argument"); return e->step_device(dx, dw); }
+int mpcq_synchronize(mpcq_engine* e) { ENTER(e); HIP_TRY(hipStreamSynchronize(e->stream)); return 0; }
 void* mpcq_stream(mpcq_engine* e) { return e ? (void*)e->stream : nullptr; }
-int mpcq_sim_reset(mpcq_engine* e, const double* x0) { CHK(e); return e->sim_reset(x0); }
-int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { CHK(e); return e->sim_steps(K, n_sub, sim_dt); }
-int mpcq_sim_run(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { CHK(e); return e->sim_run(K, n_sub, sim_dt); }
-int mpcq_sim_get_state(mpcq_engine* e, double* x, double* w) { CHK(e); return e->sim_get(x, w); }
-int mpcq_get_kernel_time(mpcq_engine* e, double* s, int32_t* n) { CHK(e); if (s) *s = e->ktime; if (n) *n = e->klaunches; return 0; }
-int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]) { CHK(e); return e->stats(out); }
+int mpcq_get_command(mpcq_engine* e, double* rotor, double* coll, double* rates) { ENTER(e); return e->get_command(rotor, coll, rates); }
+int mpcq_get_finished(mpcq_engine* e, int32_t* o) { ENTER(e); if (!o) return fail(MPCQ_ERR_INVALID, "null argument"); return e->get_finished(o); }
+int mpcq_get_reference_chunk(mpcq_engine* e, double* o) { ENTER(e); if (!o) return fail(MPCQ_ERR_INVALID, "null argument"); return e->get_chunk(o); }
+int mpcq_sim_reset(mpcq_engine* e, const double* x0) { ENTER(e); return e->sim_reset(x0); }
+int mpcq_sim_steps(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { ENTER(e); return e->sim_steps(K, n_sub, sim_dt); }
+int mpcq_sim_run(mpcq_engine* e, int32_t K, int32_t n_sub, double sim_dt) { ENTER(e); return e->sim_run(K, n_sub, sim_dt); }
+// `while control_time < optimization_dt: quad.update(w, simulation_dt); control_time += simulation_dt`
+// (src/execute_trajectory.py:232-243): the count comes out of the same double accumulation (20 / 11 / 4 at 0.1 / 0.05 / 0.02)
+int mpcq_plant_substeps(double control_dt, double sim_dt) {
+  if (!(sim_dt > 0) || !(control_dt > 0) || control_dt / sim_dt > 1e6) return -1;
+  double t = 0;
+  int n = 0;
+  while (t < control_dt) { t += sim_dt; ++n; }
+  return n;
+}
+int mpcq_sim_plant_period(mpcq_engine* e, const double* w, double control_dt, double sim_dt, int32_t* n_sub) {
+  ENTER(e);
+  const int n = mpcq_plant_substeps(control_dt, sim_dt);
+  if (n < 0) return fail(MPCQ_ERR_INVALID, "bad control_dt / sim_dt");
+  if (n_sub) *n_sub = n;
+  return e->sim_plant(w, n, sim_dt);
+}
+int mpcq_sim_control_periods(mpcq_engine* e, int32_t K, double control_dt, double sim_dt, int32_t* n_sub) {
+  ENTER(e);
+  const int n = mpcq_plant_substeps(control_dt, sim_dt);
+  if (n < 0) return fail(MPCQ_ERR_INVALID, "bad control_dt / sim_dt");
+  if (n_sub) *n_sub = n;
+  return e->sim_steps(K, n, sim_dt);
+}
+int mpcq_sim_get_state(mpcq_engine* e, double* x, double* w) { ENTER(e); return e->sim_get(x, w); }
+int mpcq_get_kernel_time(mpcq_engine* e, double* s, int32_t* n) { ENTER(e); if (s) *s = e->ktime; if (n) *n = e->klaunches; return 0; }
+int mpcq_get_kernel_time_minmax(mpcq_engine* e, double* mn, double* mx) { ENTER(e); if (mn) *mn = e->kmin; if (mx) *mx = e->kmax; return 0; }
+int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]) { ENTER(e); return e->stats(out); }
 /* diagnostic build only: per-instance phase cycle totals of the last step, [B][16] */
-int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out) { CHK(e); return e->get_prof(out); }
+int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out) { ENTER(e); return e->get_prof(out); }
 
 int mpcq_comm_unique_id(void* id128) {
   int rc = rccl_load();
@@ -644,19 +753,20 @@ int mpcq_comm_unique_id(void* id128) {
   return 0;
 }
 int mpcq_comm_init(mpcq_engine* e, int32_t rank, int32_t nranks, const void* id128) {
-  CHK(e);
+  ENTER(e);
+  if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(MPCQ_ERR_INVALID, "bad rank / nranks / id");
+  if (e->comm) return fail(MPCQ_ERR_STATE, "communicator already initialised");
   int rc = rccl_load();
   if (rc) return rc;
-  HIP_TRY(hipSetDevice(e->cfg.device));
   Id128 id;
   std::memcpy(&id, id128, sizeof(id));
   const int r = g_rccl.CommInitRank(&e->comm, nranks, id, rank);
-  if (r) return fail(MPCQ_ERR_COMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"));
+  if (r) { e->comm = nullptr; return fail(MPCQ_ERR_COMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); }
   e->nranks = nranks;
   return 0;
 }
 int mpcq_allreduce_tracking_stats(mpcq_engine* e, double out[5]) {
-  CHK(e);
+  ENTER(e);
   int rc = e->stats(nullptr);  // local 5-vector on the device
   if (rc) return rc;
   if (e->comm) {
@@ -673,7 +783,9 @@ int mpcq_allreduce_tracking_stats(mpcq_engine* e, double out[5]) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   return 0;
 }
-int mpcq_get_state(mpcq_engine* e, double* X, double* U, double* mu, double* C, double* xpp, int32_t* hp, int32_t* idx) { CHK(e); return e->get_state(X, U, mu, C, xpp, hp, idx); }
-int mpcq_set_state(mpcq_engine* e, const double* X, const double* U, const double* mu, const double* C, const double* xpp, const int32_t* hp, const int32_t* idx) { CHK(e); return e->set_state(X, U, mu, C, xpp, hp, idx); }
+int mpcq_get_state(mpcq_engine* e, double* X, double* U, double* mu, double* C, double* xpp, int32_t* hp, int32_t* idx) { ENTER(e); return e->get_state(X, U, mu, C, xpp, hp, idx); }
+int mpcq_set_state(mpcq_engine* e, const double* X, const double* U, const double* mu, const double* C, const double* xpp, const int32_t* hp, const int32_t* idx) { ENTER(e); return e->set_state(X, U, mu, C, xpp, hp, idx); }
+int mpcq_get_solver_state(mpcq_engine* e, int32_t* qp_iter, double* stats4, int32_t* finished) { ENTER(e); return e->get_solver_state(qp_iter, stats4, finished); }
+int mpcq_set_solver_state(mpcq_engine* e, const int32_t* qp_iter, const double* stats4, const int32_t* finished) { ENTER(e); return e->set_solver_state(qp_iter, stats4, finished); }
 
 }  // extern "C"

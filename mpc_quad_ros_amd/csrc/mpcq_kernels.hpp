@@ -92,6 +92,7 @@ struct DevModel {
   double imass, iJ[3];   // reciprocals formed once on the host: no divisions in the model evaluations
   double W[NY], We[NX], ulb[NU], uub[NU], uref[NU];
   double rotor_drag[3], aero_drag;
+  double finish_r;   // EPSILON_TRAJECTORY_FINISHED (src/mpc_controller_node.py:118)
   TQ qp_tol;    // final KKT tolerance (IPM-only fallback)
   TQ ipm_tol;   // IPM -> active-set polish hand-over tolerance
   TQ eps;       // unit roundoff scale of TQ used for KKT sign / bound tests
@@ -120,6 +121,7 @@ struct DevState {
   const int* tlen;
   int* status;
   int* qp_iter;
+  int* finished;    // [B] trajectory finished (src/mpc_controller_node.py:374), sticky until new trajectories / reset
   TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
   double* run_x;    // [B][13] plant states of the free-running closed loop (MODE_RUN; aliases x_meas)
   int run_steps, run_nsub;   // control periods per launch, plant substeps per period
@@ -1638,6 +1640,14 @@ __device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, T
 // ------------------------------------------------------------------ the fused step kernel
 // reference row (get_reference_chunk, src/utils/utils.py:897-931) for horizon node j
 __device__ inline long chunk_row(int j, int have, int idx, int skip, int len) { return j < have ? (long)idx + (long)j * skip : (long)len - 1; }
+// number of chunk rows taken from the trajectory itself (the rest repeat its last row): all N while more than N*skip
+// rows are left, the clipped strided slice ceil(left/skip) while more than skip-1 are left, none after that
+__device__ inline int chunk_have(int len, int idx, int N, int skip) {
+  const long left = (long)len - idx;
+  if (left > (long)N * skip) return N;
+  if (left > skip - 1) { const long h = (left + skip - 1) / skip; return h > N ? N : (int)h; }
+  return 0;
+}
 
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
@@ -1669,9 +1679,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   const double* tr = nullptr;
   if (mode & MODE_TRAJ) {
     len = st.tlen[b];
-    const long left = (long)len - idx;
-    if (left > (long)N * m.skip) have = N;
-    else if (left > m.skip - 1) { have = (int)((left + m.skip - 1) / m.skip); if (have > N) have = N; }
+    have = chunk_have(len, idx, N, m.skip);
     tr = st.traj + (size_t)b * m.Tmax * NX;
   }
   const double* gy = st.yref + (size_t)b * N * NY;
@@ -1705,10 +1713,11 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
       for (int k = 0; k < NU; ++k) u[k] = st.w[(size_t)b * NU + k];
       for (int sub = 0; sub < st.run_nsub; ++sub) plant_rk4(m, x, u, st.run_dt);
 #pragma unroll
-      for (int k = 0; k < NX; ++k) st.run_x[(size_t)b * NX + k] = x[k];
+      for (int k = 0; k < NX; ++k) { st.run_x[(size_t)b * NX + k] = x[k]; D[L.x0 + k] = x[k]; }   // the new plant state IS this period's measurement
     }
   }
-  const double xm = tid < NX ? st.x_meas[(size_t)b * NX + tid] : 0.0;
+  const bool meas_from_plant = (mode & MODE_PLANT_FIRST) != 0;   // then lane 0 has already put it into LDS (no store -> load hand-over through memory)
+  const double xm = (tid < NX && !meas_from_plant) ? st.x_meas[(size_t)b * NX + tid] : 0.0;
   if (gp) {   // mu -> LDS scratch (shooting records are not live yet); rows of Kx^-1 come straight from L2
     for (int i = tid; i < 3 * nb; i += 64) { S[L.sub + i] = gmu[i]; S[L.basis + i] = m.basis[i]; }
   }
@@ -1721,7 +1730,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     S[L.lb + it] = (TQ)(m.ulb[k] - u);
     S[L.ub + it] = (TQ)(m.uub[k] - u);
   }
-  if (tid < NX) D[L.x0 + tid] = xm;
+  if (tid < NX && !meas_from_plant) D[L.x0 + tid] = xm;
   // X -> LDS and qv = Q_i (X_i - xref_i) in one pass over the record
   for (int base = 0; base < (N + 1) * NX; base += 64 * UNR) {
     if (base > 0) load_block(base);
@@ -1874,6 +1883,9 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     }
     double* gs = st.stats + (size_t)b * 4;
     gs[0] += ep; gs[1] += ev; gs[2] += 1; gs[3] = tmax(gs[3], ep);
+    // trajectory finished (src/mpc_controller_node.py:374, evaluated after idx_traj += 1): the cursor stands on the last
+    // row and the quadrotor is within EPSILON_TRAJECTORY_FINISHED of the first row of this step's chunk
+    if ((mode & MODE_TRAJ) && idx + 2 == len && sqrt(ep) < m.finish_r) st.finished[b] = 1;
   }
   __syncthreads();
   if (gp) rgp_regress<C>(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3, true);
@@ -1936,6 +1948,35 @@ __global__ void plant_kernel(const DevModel<TQ> m, double* xs, const double* w, 
   for (int s = 0; s < n_sub; ++s) plant_rk4(m, x, u, sim_dt);
 #pragma unroll
   for (int k = 0; k < NX; ++k) xs[(size_t)b * NX + k] = x[k];
+}
+
+// publish_control_gazebo (src/mpc_controller_node.py:600-612): rotor_thrusts = w T_max / m, collective_thrust =
+// sum(w) T_max / m, body rates = x_opt[1, 10:13]; same operation order as the numpy expressions
+template <typename TQ>
+__global__ void command_kernel(const DevModel<TQ> m, const double* w, const double* X, double* rotor, double* coll, double* rates, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const double wk = w[(size_t)b * NU + k];
+    rotor[(size_t)b * NU + k] = wk * m.tmax / m.mass;
+    s += wk;
+  }
+  coll[b] = s * m.tmax / m.mass;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) rates[(size_t)b * 3 + k] = X[(size_t)b * (m.N + 1) * NX + NX + 10 + k];
+}
+
+// get_reference_chunk at the current cursor, with the same row selection the step kernel uses: out [B][N][13]
+template <typename TQ>
+__global__ void chunk_kernel(const DevModel<TQ> m, const double* traj, const int* tlen, const int* idx, double* out) {
+  const int b = blockIdx.x;
+  const int len = tlen[b], id = idx[b], have = chunk_have(len, id, m.N, m.skip);
+  for (int it = threadIdx.x; it < m.N * NX; it += blockDim.x) {
+    const int j = it / NX, k = it - j * NX;
+    out[(size_t)b * m.N * NX + it] = traj[((size_t)b * m.Tmax + chunk_row(j, have, id, m.skip, len)) * NX + k];
+  }
 }
 
 // reduce per-instance statistics to 5 numbers (sum, sum, sum, max, #failed)

@@ -156,6 +156,60 @@ class Engine:
         self._check(self.lib.mpcq_sim_get_state(self.h, _lib.d(x), _lib.d(w)))
         return x, w
 
+    # ---- outputs of the loop body beyond w (a4, a9)
+    def get_command(self):
+        """(rotor_thrusts [B,4], collective_thrust [B], bodyrates [B,3]) of publish_control_gazebo."""
+        rotor, coll, rates = np.zeros((self.B, NU)), np.zeros(self.B), np.zeros((self.B, 3))
+        self._check(self.lib.mpcq_get_command(self.h, _lib.d(rotor), _lib.d(coll), _lib.d(rates)))
+        return rotor, coll, rates
+
+    def get_finished(self):
+        out = np.zeros(self.B, np.int32)
+        self._check(self.lib.mpcq_get_finished(self.h, _lib.i(out)))
+        return out
+
+    def get_reference_chunk(self):
+        out = np.zeros((self.B, self.N, NX))
+        self._check(self.lib.mpcq_get_reference_chunk(self.h, _lib.d(out)))
+        return out
+
+    def plant_substeps(self, control_dt, sim_dt=5e-3):
+        return int(self.lib.mpcq_plant_substeps(float(control_dt), float(sim_dt)))
+
+    def sim_plant_period(self, w, control_dt, sim_dt=5e-3):
+        """Advance the plant state by the reference's float-accumulated substep loop; returns the substep count."""
+        w = self._f(w, (self.B, NU))
+        n = ctypes.c_int32()
+        self._check(self.lib.mpcq_sim_plant_period(self.h, _lib.d(w), float(control_dt), float(sim_dt), ctypes.byref(n)))
+        return n.value
+
+    def sim_control_periods(self, K, control_dt, sim_dt=5e-3):
+        n = ctypes.c_int32()
+        self._check(self.lib.mpcq_sim_control_periods(self.h, int(K), float(control_dt), float(sim_dt), ctypes.byref(n)))
+        return n.value
+
+    def step_device_async(self, d_x_meas: int, d_w_out: int = 0):
+        """Fused step on float64 device buffers (raw device addresses); asynchronous on the engine's stream."""
+        self._check(self.lib.mpcq_step_device_async(self.h, ctypes.c_void_p(d_x_meas), ctypes.c_void_p(d_w_out or None)))
+
+    def synchronize(self):
+        self._check(self.lib.mpcq_synchronize(self.h))
+
+    def get_solver_state(self):
+        s = dict(qp_iter=np.zeros(self.B, np.int32), stats=np.zeros((self.B, 4)), finished=np.zeros(self.B, np.int32))
+        self._check(self.lib.mpcq_get_solver_state(self.h, _lib.i(s["qp_iter"]), _lib.d(s["stats"]), _lib.i(s["finished"])))
+        return s
+
+    def set_solver_state(self, qp_iter=None, stats=None, finished=None):
+        g = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        q, f, st = g(qp_iter), g(finished), self._f(stats)
+        self._check(self.lib.mpcq_set_solver_state(self.h, _lib.i(q), _lib.d(st), _lib.i(f)))
+
+    def get_kernel_time_minmax(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        self._check(self.lib.mpcq_get_kernel_time_minmax(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def get_kernel_time(self):
         t = ctypes.c_double()
         n = ctypes.c_int32()

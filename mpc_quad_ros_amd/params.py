@@ -83,6 +83,7 @@ class CConfig(ctypes.Structure):
         # --- product-only tail (the oracle's struct ends above)
         ("device", ctypes.c_int32), ("precision", ctypes.c_int32),
         ("qp_max_iter", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("finish_radius", ctypes.c_double),
     ]
 
 
@@ -111,6 +112,7 @@ class EngineConfig:
     device: int = 0
     precision: int = PRECISION_F64
     qp_max_iter: int = 0              # 0 -> implementation default
+    finish_radius: float = 0.0        # EPSILON_TRAJECTORY_FINISHED [m]; 0 -> 1.0 (src/mpc_controller_node.py:118)
 
     def __post_init__(self):
         if self.skip is None:
@@ -152,6 +154,7 @@ class EngineConfig:
         c.basis = self._basis_buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         c.theta = self._theta_buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         c.device, c.precision, c.qp_max_iter, c.reserved = self.device, self.precision, self.qp_max_iter, 0
+        c.finish_radius = float(self.finish_radius)
         return c
 
 

@@ -31,6 +31,9 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace {
 
@@ -296,10 +299,22 @@ bool invert(const std::vector<double>& A, int n, std::vector<double>& Ai) {
 // src/_acados_ocp.json:2085,2104-2116).  Mehrotra predictor-corrector to mu ~ 1e-13, then an
 // active-set polish that solves the KKT system of the identified active set exactly.
 // returns iterations (>0) or negative on failure.
+// Scratch of one solve, kept per thread and reused from call to call (the batched driver runs thousands of solves per
+// thread: allocating ~0.5 MB of std::vectors in every one of them serialises the OpenMP threads on the heap).
+struct Work {
+  std::vector<double> sl, su, ll, lu, rd, dz, dza, M, rhs, dll, dlu, zz, grad, Hf, bf;
+  std::vector<int> act, fr;
+  std::vector<double> alpha, AB, c, d, G, H, g, lb, ub, z, dx, chunk;
+};
+Work& work() { static thread_local Work w; return w; }
+
 int box_qp(int n, const std::vector<double>& H, const std::vector<double>& g, const std::vector<double>& lb,
            const std::vector<double>& ub, std::vector<double>& z, double tol, double* kkt_out) {
-  std::vector<double> sl(n), su(n), ll(n), lu(n), rd(n), dz(n), dza(n), M(n * n), rhs(n);
-  std::vector<double> dll(n), dlu(n);
+  Work& ws = work();
+  std::vector<double>&sl = ws.sl, &su = ws.su, &ll = ws.ll, &lu = ws.lu, &rd = ws.rd, &dz = ws.dz, &dza = ws.dza, &M = ws.M, &rhs = ws.rhs;
+  std::vector<double>&dll = ws.dll, &dlu = ws.dlu;
+  for (std::vector<double>* v : {&sl, &su, &ll, &lu, &rd, &dz, &dza, &rhs, &dll, &dlu}) v->assign(n, 0.0);
+  M.assign((size_t)n * n, 0.0);
   double gmax = 1.0;
   for (int i = 0; i < n; ++i) gmax = std::max(gmax, std::fabs(g[i]));
   for (int i = 0; i < n; ++i) {
@@ -378,22 +393,26 @@ int box_qp(int n, const std::vector<double>& H, const std::vector<double>& g, co
     }
   }
   // ---- active-set polish
-  std::vector<int> act(n, 0);  // -1 lower, +1 upper, 0 free
+  std::vector<int>& act = ws.act;  // -1 lower, +1 upper, 0 free
+  act.assign(n, 0);
   for (int i = 0; i < n; ++i) {
     if (ll[i] > sl[i]) act[i] = -1;
     else if (lu[i] > su[i]) act[i] = 1;
   }
-  std::vector<double> zz(n), grad(n);
+  std::vector<double>&zz = ws.zz, &grad = ws.grad;
+  zz.assign(n, 0.0); grad.assign(n, 0.0);
   double kkt = 1e300;
   for (int pass = 0; pass < 4 * n + 10; ++pass) {
-    std::vector<int> fr;
+    std::vector<int>& fr = ws.fr;
+    fr.clear();
     for (int i = 0; i < n; ++i) {
       if (act[i] == 0) fr.push_back(i);
       else zz[i] = act[i] < 0 ? lb[i] : ub[i];
     }
     const int nf = (int)fr.size();
     if (nf) {
-      std::vector<double> Hf(nf * nf), bf(nf);
+      std::vector<double>&Hf = ws.Hf, &bf = ws.bf;
+      Hf.assign((size_t)nf * nf, 0.0); bf.assign(nf, 0.0);
       for (int a = 0; a < nf; ++a) {
         double t = -g[fr[a]];
         for (int j = 0; j < n; ++j)
@@ -448,7 +467,8 @@ RtiOut rti_solve(const Model& m, double* X, double* U, const double* x0, const d
   const int N = m.N, nv = NU * N;
   const double h = m.T / N;  // optimization_dt, src/quad_opt.py:43
   RtiOut out{0, 0, 0, 0};
-  std::vector<double> alpha;
+  Work& ws = work();
+  std::vector<double>& alpha = ws.alpha;
   const double* al = nullptr;
   if (m.nb > 0 && mu) {
     alpha.assign(3 * m.nb, 0.0);
@@ -461,14 +481,16 @@ RtiOut rti_solve(const Model& m, double* X, double* U, const double* x0, const d
     al = alpha.data();
   }
   // 1. shooting: phi_i, [A_i|B_i], gap c_i = phi_i - X_{i+1}
-  std::vector<double> AB(N * NX * NY), c(N * NX);
+  std::vector<double>&AB = ws.AB, &c = ws.c;
+  AB.assign((size_t)N * NX * NY, 0.0); c.assign((size_t)N * NX, 0.0);
   for (int i = 0; i < N; ++i) {
     double phi[NX];
     rk4_sens(m, X + i * NX, U + i * NU, al, h, phi, &AB[i * NX * NY]);
     for (int k = 0; k < NX; ++k) c[i * NX + k] = phi[k] - X[(i + 1) * NX + k];
   }
   // 2. condensing.  dx_i = d_i + sum_{j<i} G[i][j] du_j ; d_0 = x0 - X_0 (lbx=ubx=x_init, :328-329)
-  std::vector<double> d((N + 1) * NX), G((size_t)(N + 1) * N * NX * NU, 0.0);
+  std::vector<double>&d = ws.d, &G = ws.G;
+  d.assign((size_t)(N + 1) * NX, 0.0); G.assign((size_t)(N + 1) * N * NX * NU, 0.0);
   auto Gb = [&](int i, int j) { return &G[((size_t)i * N + j) * NX * NU]; };
   for (int k = 0; k < NX; ++k) d[k] = x0[k] - X[k];
   for (int i = 0; i < N; ++i) {
@@ -493,7 +515,8 @@ RtiOut rti_solve(const Model& m, double* X, double* U, const double* x0, const d
       for (int cc = 0; cc < NU; ++cc) Go[r * NU + cc] = A[r * NY + NX + cc];
   }
   // cost: stage i<N weight h*W (acados scales LS stage costs by the interval; terminal unscaled)
-  std::vector<double> H(nv * nv, 0.0), g(nv, 0.0), lb(nv), ub(nv), z(nv);
+  std::vector<double>&H = ws.H, &g = ws.g, &lb = ws.lb, &ub = ws.ub, &z = ws.z;
+  H.assign((size_t)nv * nv, 0.0); g.assign(nv, 0.0); lb.assign(nv, 0.0); ub.assign(nv, 0.0); z.assign(nv, 0.0);
   for (int i = 1; i <= N; ++i) {
     double qd[NX], e[NX];
     for (int k = 0; k < NX; ++k) {
@@ -536,7 +559,8 @@ RtiOut rti_solve(const Model& m, double* X, double* U, const double* x0, const d
   out.kkt = kkt;
   if (it < 0) { out.status = 4; return out; }  // ACADOS_QP_FAILURE
   // 4. expand + full step (nlp_solver_step_length 1.0, src/_acados_ocp.json:2094)
-  std::vector<double> dx((N + 1) * NX);
+  std::vector<double>& dx = ws.dx;
+  dx.assign((size_t)(N + 1) * NX, 0.0);
   for (int k = 0; k < NX; ++k) dx[k] = d[k];
   for (int i = 0; i < N; ++i) {
     const double* A = &AB[i * NX * NY];
@@ -580,7 +604,8 @@ void rgp_setup(Model& m) {
 // (src/gp/RGP.py:199-208) for ONE new point (s, y) on axis d.  Operation order follows numpy's.
 void rgp_regress_axis(const Model& m, int d, double s, double y, double* mu, double* C) {
   const int n = m.nb;
-  std::vector<double> ks(n), Jt(n), JC(n), G(n), GJ(n * n), Cn(n * n);
+  static thread_local std::vector<double> ks, Jt, JC, G, GJ, Cn;
+  ks.assign(n, 0.0); Jt.assign(n, 0.0); JC.assign(n, 0.0); G.assign(n, 0.0); GJ.assign((size_t)n * n, 0.0); Cn.assign((size_t)n * n, 0.0);
   for (int j = 0; j < n; ++j) ks[j] = rbf(s, m.Xb[d][j], m.L[d], m.sf[d]);
   for (int j = 0; j < n; ++j) {
     double t = 0;
@@ -705,7 +730,7 @@ struct Engine {
   Model m;
   int B = 0;
   std::vector<double> X, U, mu, C, xpred_prev, cost, kkt;
-  std::vector<int> has_prev, idx, status, qp_iter;
+  std::vector<int> has_prev, idx, status, qp_iter, finished;
   std::vector<double> traj;  // [B][Tmax][13]
   std::vector<int> tlen;
   int Tmax = 0;
@@ -726,6 +751,7 @@ void engine_reset(Engine& e) {
   std::fill(e.idx.begin(), e.idx.end(), 0);
   std::fill(e.status.begin(), e.status.end(), 0);
   std::fill(e.qp_iter.begin(), e.qp_iter.end(), 0);
+  std::fill(e.finished.begin(), e.finished.end(), 0);
   std::fill(e.cost.begin(), e.cost.end(), 0.0);
   std::fill(e.stats.begin(), e.stats.end(), 0.0);
 }
@@ -778,7 +804,7 @@ void* orc_create(const orc_config* c) {
   e->mu.assign((size_t)B * 3 * m.nb, 0.0);
   e->C.assign((size_t)B * 3 * m.nb * m.nb, 0.0);
   e->xpred_prev.assign((size_t)B * NX, 0.0);
-  e->has_prev.assign(B, 0); e->idx.assign(B, 0); e->status.assign(B, 0); e->qp_iter.assign(B, 0);
+  e->has_prev.assign(B, 0); e->idx.assign(B, 0); e->status.assign(B, 0); e->qp_iter.assign(B, 0); e->finished.assign(B, 0);
   e->cost.assign(B, 0.0); e->kkt.assign(B, 0.0);
   e->yref.assign((size_t)B * m.N * NY, 0.0); e->yrefN.assign((size_t)B * NX, 0.0);
   e->stats.assign((size_t)B * 4, 0.0);
@@ -793,7 +819,7 @@ void orc_set_trajectories(void* h, const double* traj, const int32_t* len, int T
   Engine& e = *(Engine*)h;
   e.Tmax = Tmax;
   e.traj.assign(traj, traj + (size_t)e.B * Tmax * NX);
-  for (int b = 0; b < e.B; ++b) { e.tlen[b] = len[b]; e.idx[b] = 0; }
+  for (int b = 0; b < e.B; ++b) { e.tlen[b] = len[b]; e.idx[b] = 0; e.finished[b] = 0; }
 }
 void orc_set_reference(void* h, const double* yref, const double* yrefN) {
   Engine& e = *(Engine*)h;
@@ -918,7 +944,8 @@ void orc_step(void* h, const double* x_meas, double* w_out, double* x_pred_out) 
 #pragma omp parallel for schedule(static)
   for (int b = 0; b < e.B; ++b) {
     const double* x = x_meas + (size_t)b * NX;
-    std::vector<double> chunk(N * NX);
+    std::vector<double>& chunk = work().chunk;
+    chunk.assign((size_t)N * NX, 0.0);
     reference_chunk(&e.traj[(size_t)b * e.Tmax * NX], e.tlen[b], e.idx[b], N, m.skip, chunk.data());
     double* yref = &e.yref[(size_t)b * N * NY];
     double* yrefN = &e.yrefN[(size_t)b * NX];
@@ -931,6 +958,11 @@ void orc_step(void* h, const double* x_meas, double* w_out, double* x_pred_out) 
     double xp[NX];
     rk4(m, x, w, nullptr, m.dt_pred, xp);  // quad_nominal.discrete_dynamics
     e.idx[b] += 1;
+    {  // trajectory finished, src/mpc_controller_node.py:374 (EPSILON_TRAJECTORY_FINISHED = 1 m, :118), x_ref = this step's chunk
+      double e2 = 0;
+      for (int k = 0; k < 3; ++k) e2 += (x[k] - chunk[k]) * (x[k] - chunk[k]);
+      if (e.idx[b] + 1 == e.tlen[b] && std::sqrt(e2) < 1.0) e.finished[b] = 1;
+    }
     if (n) {
       const double* xpm1 = e.has_prev[b] ? &e.xpred_prev[(size_t)b * NX] : x;
       double vb[3], ad[3];
@@ -974,6 +1006,32 @@ int orc_plant_control_period(void* h, double* x, const double* u, double control
     if (b == 0) n = k;
   }
   return n;
+}
+
+// trajectory-finished flags (src/mpc_controller_node.py:374) and the command mapping of publish_control_gazebo
+// (src/mpc_controller_node.py:600-612) for the last solve
+void orc_get_finished(void* h, int32_t* out) { Engine& e = *(Engine*)h; std::copy(e.finished.begin(), e.finished.end(), out); }
+void orc_get_command(void* h, double* rotor, double* coll, double* rates) {
+  Engine& e = *(Engine*)h;
+  const Model& m = e.m;
+  for (int b = 0; b < e.B; ++b) {
+    const double* w = &e.U[(size_t)b * m.N * NU];   // w = w_opt[0, :]
+    double s = 0;
+    for (int k = 0; k < NU; ++k) { rotor[(size_t)b * NU + k] = w[k] * m.tmax / m.mass; s += w[k]; }
+    coll[b] = s * m.tmax / m.mass;
+    for (int k = 0; k < 3; ++k) rates[(size_t)b * 3 + k] = e.X[((size_t)b * (m.N + 1) + 1) * NX + 10 + k];   // x_opt[1, 10:13]
+  }
+}
+// OpenMP team size of the batched entry points (the bench sweeps it); returns the previous maximum
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  const int prev = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  return prev;
+#else
+  (void)n;
+  return 1;
+#endif
 }
 
 }  // extern "C"

@@ -49,6 +49,8 @@ def load(native: bool = False):
             getattr(lib, name).argtypes = [ctypes.c_void_p]
             getattr(lib, name).restype = None
         lib.orc_plant_control_period.restype = ctypes.c_int
+        lib.orc_set_threads.restype = ctypes.c_int
+        lib.orc_set_threads.argtypes = [ctypes.c_int]
         _libs[native] = lib
     return _libs[native]
 
@@ -175,6 +177,19 @@ class OracleEngine:
         xp = np.zeros((self.B, NX))
         self.lib.orc_step(self.h, _d(x), _d(w), _d(xp))
         return w, xp
+
+    def get_finished(self):
+        out = np.zeros(self.B, np.int32)
+        self.lib.orc_get_finished(self.h, _i(out))
+        return out
+
+    def get_command(self):
+        rotor, coll, rates = np.zeros((self.B, NU)), np.zeros(self.B), np.zeros((self.B, 3))
+        self.lib.orc_get_command(self.h, _d(rotor), _d(coll), _d(rates))
+        return rotor, coll, rates
+
+    def set_threads(self, n):
+        return self.lib.orc_set_threads(int(n))
 
     def get_tracking_stats(self):
         out = np.zeros(4)

@@ -65,19 +65,47 @@ def test_emu_lane_order_independent(monkeypatch):
     assert float(out) == w_fwd
 
 
+def _closed_loop_digest():
+    """Lockstep launches with the plant at their head (MODE_PLANT_FIRST) and the free-running launch, as a number."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N, nb = 2, 10, 10
+    traj, lens = swarm_trajectories(3, 0, B)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    out = []
+    for mode in ("sim_steps", "sim_run"):
+        e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb)))
+        e.set_trajectories(traj, lens); e.sim_reset(x0)
+        getattr(e, mode)(4, 2, 5e-3)
+        x, w = e.sim_get_state()
+        out.append(float(np.sum(x * np.arange(1, 14)) + np.sum(w)))
+    return out
+
+
+def test_emu_lane_order_independent_closed_loop():
+    # the plant -> measurement hand-over inside a launch (lane 0 writes, lanes 0..12 read) must not depend on lane order
+    fwd = _closed_loop_digest()
+    assert fwd[0] == fwd[1]
+    env = dict(os.environ, MPCQ_EMU_REVERSE="1")
+    code = ("import sys; sys.path[:0]=[%r,%r]; import test_emu_parity as t; print(repr(t._closed_loop_digest()))") % (
+        os.path.dirname(EMU_DIR), os.path.dirname(os.path.dirname(EMU_DIR)))
+    out = subprocess.check_output(["python", "-c", code], env=env).decode().strip().splitlines()[-1]
+    assert eval(out) == fwd
+
+
 def test_emu_f32_qp_mode_within_budget():
     # TQ = float: state and QP data still formed in double; north_star budget 1e-4 relative control deviation
     assert pc.case_swarm_closed_loop(make, B=2, N=20, nb=10, K=10, precision=1) < 1e-4
 
 
-def test_emu_facade_mirrors_quad_optimizer():
+def test_emu_facade_mirrors_quad_optimizer(lib=EMU):
     from mpc_quad_ros_amd.quad_opt import quad_optimizer
     from mpc_quad_ros_amd.params import hummingbird, rgp_basis_linspace
     from mpc_quad_ros_amd.host_math import compute_a_drag
     from oracle.oracle import OracleEngine
     B, N, nb = 2, 5, 10
     gpe = dict(basis=rgp_basis_linspace(12.0, nb), theta=[1.0, 0.1, 0.1])
-    qo = quad_optimizer(hummingbird(), t_horizon=1, n_nodes=N, gpe=gpe, batch=B, lib_path=EMU)
+    qo = quad_optimizer(hummingbird(), t_horizon=1, n_nodes=N, gpe=gpe, batch=B, lib_path=lib)
     assert qo.optimization_dt == 1 / N and qo.gpe.type == "RGP" and qo.gpe.gp[0].X.shape == (nb,)
     with pytest.raises(ValueError):
         qo.run_optimization(None)

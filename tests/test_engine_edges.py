@@ -138,7 +138,116 @@ def _free_running_equals_lockstep(lib):
         assert (res[0][4] == K + 2).all()
 
 
-CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log, _free_running_equals_lockstep]
+def _command_and_finished(lib):
+    """a4: the command mapping of publish_control_gazebo (src/mpc_controller_node.py:600-612), bit-exact against the
+    numpy expressions; a9: the finished predicate (src/mpc_controller_node.py:374) against the oracle's flags."""
+    B, N, nb = 4, 5, 10
+    kw = dict(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), skip=1)
+    e, o = engines(lib, **kw)
+    T = 12
+    traj = np.zeros((B, T, 13)); traj[:, :, 3] = 1.0; traj[:, :, 2] = 3.0
+    traj[:, :, 0] = np.linspace(0, 0.3, T)[None, :]
+    traj[3, :, 0] += 5.0                                  # quadrotor 3 never gets within 1 m of its reference: never finishes
+    lens = np.array([T, T - 3, 6, T], dtype=np.int32)     # different lengths: flags rise at different steps
+    e.set_trajectories(traj, lens); o.set_trajectories(traj, lens)
+    x = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    q = hummingbird()
+    seen = []
+    for k in range(T + 2):
+        w, xp = e.step(x); wo, xpo = o.step(x)
+        rotor, coll, rates = e.get_command()
+        assert np.array_equal(rotor, w * q.max_thrust / q.mass)
+        assert np.array_equal(coll, np.sum(w, axis=1) * q.max_thrust / q.mass)
+        assert np.array_equal(rates, e.get_x(1)[:, 10:13])
+        ro, co, rao = o.get_command()
+        assert np.abs(rotor - ro).max() < 1e-6 and np.abs(coll - co).max() < 1e-6 and np.abs(rates - rao).max() < 1e-6
+        assert np.array_equal(e.get_finished(), o.get_finished()), k
+        seen.append(e.get_finished().copy())
+        x = xpo
+    seen = np.array(seen)
+    # idx_traj + 1 == len is tested after the increment: the flag rises in the step whose cursor was len - 2, and stays
+    for b in range(3):
+        assert seen[:, b].tolist() == [0] * (lens[b] - 2) + [1] * (T + 2 - (lens[b] - 2))
+    assert not seen[:, 3].any()
+    e.set_trajectories(traj, lens)
+    assert not e.get_finished().any()                     # a new trajectory clears the flag (trajectory_received_cb)
+
+
+def _chunk_cases_on_device(lib):
+    """All 1 239 get_reference_chunk cases generated by executing the reference's function
+    (tests/golden/utils_vectors.npz), pushed through the device-side row selection the fused step uses."""
+    from helpers import load_golden
+    v = load_golden("utils_vectors.npz")
+    rng = np.random.default_rng(0)
+    groups = {}
+    for (T, N, skip, idx), rows in zip(v["chunk_cases"], v["chunk_rows"]):
+        groups.setdefault((int(N), int(skip)), []).append((int(T), int(idx), rows))
+    total = 0
+    for (N, skip), cases in sorted(groups.items()):
+        B, Tmax = len(cases), max(c[0] for c in cases)
+        e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), skip=skip), lib_path=lib)
+        traj = rng.normal(size=(B, Tmax, 13))
+        lens = np.array([c[0] for c in cases], dtype=np.int32)
+        e.set_trajectories(traj, lens)
+        e.set_state(idx=np.array([c[1] for c in cases], dtype=np.int32))
+        ch = e.get_reference_chunk()
+        for b, (T, idx, rows) in enumerate(cases):
+            assert np.array_equal(ch[b], traj[b][rows[:N]]), (T, N, skip, idx)
+        total += B
+        e.close()
+    assert total == len(v["chunk_cases"]) == 1239
+
+
+def _plant_period_matches_reference_logs(lib):
+    """f1: the device plant with the reference's float-accumulated substep loop (src/execute_trajectory.py:232-243)
+    against the logged python-simulation states: x_odom[k+1] = plant(x_odom[k], w_odom[k]), 20 substeps of 5 ms."""
+    from helpers import config_for_log, load_golden
+    for name, K in (("log_traj1_v10_a10_gp0.npz", 120), ("log_traj0_v10_a10_gp2.npz", 100)):
+        g = load_golden(name)
+        cfg = config_for_log(g, batch=K)
+        e = Engine(cfg, lib_path=lib)
+        assert [e.plant_substeps(d) for d in (0.1, 0.05, 0.02)] == [20, 11, 4]      # SURVEY V9
+        e.sim_reset(g["x_odom"][:K])
+        n = e.sim_plant_period(g["w_odom"][:K], cfg.optimization_dt, 5e-3)
+        assert n == 20
+        x, w = e.sim_get_state()
+        assert np.abs(x - g["x_odom"][1:K + 1]).max() < 1e-12
+        assert np.array_equal(w, g["w_odom"][:K])
+        o = OracleEngine(config_for_log(g, batch=K))
+        xo, no = o.plant_control_period(g["x_odom"][:K], g["w_odom"][:K], cfg.optimization_dt, 5e-3)
+        assert no == n and np.abs(x - xo).max() < 1e-13
+        e.close()
+
+
+def _checkpoint_resume_is_bitwise(lib):
+    """get_state + get_solver_state + sim_get_state is the whole resumable state: an engine restored from a dump
+    continues bit for bit (warm-start flag, tracking accumulators and finished flags included)."""
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N, nb, K1, K2 = (32, 20, 10, 30, 25) if lib is None else (2, 10, 10, 4, 3)
+    kw = dict(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb))
+    traj, lens = swarm_trajectories(9, 0, B)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    a = Engine(EngineConfig(**kw), lib_path=lib)
+    a.set_trajectories(traj, lens); a.sim_reset(x0)
+    a.sim_control_periods(K1, 0.01, 5e-3)
+    dump = (a.get_state(), a.get_solver_state(), a.sim_get_state()[0])
+    assert (dump[1]["qp_iter"] > 0).all() and (dump[1]["stats"][:, 2] == K1).all()
+    a.sim_control_periods(K2, 0.01, 5e-3)
+    b = Engine(EngineConfig(**kw), lib_path=lib)
+    b.set_trajectories(traj, lens)
+    b.set_state(**dump[0]); b.set_solver_state(**dump[1]); b.sim_reset(dump[2])
+    b.sim_control_periods(K2, 0.01, 5e-3)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    for k, va in a.get_solver_state().items():
+        assert np.array_equal(va, b.get_solver_state()[k]), k
+    assert np.array_equal(a.sim_get_state()[0], b.sim_get_state()[0]) and np.array_equal(a.sim_get_state()[1], b.sim_get_state()[1])
+    assert np.array_equal(a.get_tracking_stats(), b.get_tracking_stats())
+
+
+CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log, _free_running_equals_lockstep,
+         _command_and_finished, _chunk_cases_on_device, _plant_period_matches_reference_logs, _checkpoint_resume_is_bitwise]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.__name__.strip("_") for c in CASES])

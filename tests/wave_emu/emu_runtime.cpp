@@ -73,7 +73,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 struct emuEvent { std::chrono::steady_clock::time_point t; };
 const char* hipGetErrorString(hipError_t) { return "emu"; }
 hipError_t hipGetDeviceCount(int* n) { *n = 8; return hipSuccess; }   // pretend an 8-GPU node so multi-rank tests can use LOCAL_RANK as the ordinal
-hipError_t hipSetDevice(int) { return hipSuccess; }
+static thread_local int emu_device = 0;
+hipError_t hipSetDevice(int d) { emu_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = emu_device; return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
@@ -82,6 +84,10 @@ hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
+  for (size_t r = 0; r < h; ++r) std::memmove((char*)d + r * dp, (const char*)s + r * sp, w);
+  return hipSuccess;
+}
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

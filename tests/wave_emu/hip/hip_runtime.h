@@ -164,6 +164,7 @@ constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
 const char* hipGetErrorString(hipError_t);
 hipError_t hipGetDeviceCount(int*);
 hipError_t hipSetDevice(int);
+hipError_t hipGetDevice(int*);
 #define hipHostMallocDefault 0
 hipError_t hipHostMalloc(void**, size_t, unsigned);
 hipError_t hipHostFree(void*);
@@ -174,6 +175,7 @@ hipError_t hipFree(void*);
 hipError_t hipMemset(void*, int, size_t);
 hipError_t hipMemsetAsync(void*, int, size_t, hipStream_t);
 hipError_t hipMemcpyAsync(void*, const void*, size_t, hipMemcpyKind, hipStream_t);
+hipError_t hipMemcpy2DAsync(void*, size_t, const void*, size_t, size_t, size_t, hipMemcpyKind, hipStream_t);
 hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned);
 hipError_t hipStreamSynchronize(hipStream_t);
 hipError_t hipStreamDestroy(hipStream_t);

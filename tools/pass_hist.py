@@ -14,6 +14,7 @@ e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis
 traj, lens = swarm_trajectories(2026, 0, B)
 e.set_trajectories(traj, lens)
 e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
+e.sim_steps(int(os.environ.get('PREROLL', '150')), 2, 5e-3)   # same regime as bench.py
 hist = collections.Counter(); permax = []; kt = []
 for k in range(steps):
     e.sim_steps(1, 2, 5e-3)

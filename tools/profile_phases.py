@@ -26,7 +26,7 @@ def main():
     traj, lens = swarm_trajectories(2026, 0, B)
     e.set_trajectories(traj, lens)
     e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
-    e.lib.mpcq_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    e.sim_steps(int(os.environ.get('PREROLL', '150')), 2, 5e-3)   # same regime as bench.py
     acc = np.zeros((B, 16))
     mx = np.zeros(16)
     its = []
