@@ -70,7 +70,7 @@ _cache = {}
 
 
 def load(path: str | None = None):
-    path = os.path.abspath(path or DEFAULT_LIB)
+    path = os.path.abspath(path or os.environ.get("MPCQ_LIB") or DEFAULT_LIB)   # MPCQ_LIB: experiment builds (csrc/Makefile `variant`)
     if path in _cache:
         return _cache[path]
     if not os.path.exists(path):

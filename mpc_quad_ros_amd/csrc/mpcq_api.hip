@@ -239,6 +239,8 @@ struct EngineT : mpcq_engine {
     if (const char* t = getenv("MPCQ_POLISH_MAX")) m.polish_max = atoi(t);
     m.warm_max = f32 ? 12 : 24;   // passes of the warm active-set attempt before falling back to the IPM
     if (const char* t = getenv("MPCQ_WARM_MAX")) m.warm_max = atoi(t);
+    m.pdas_max = 0;   // passes in which pins and releases may happen together (fp64 active-set method; measured on the bench workload: such passes are rare, 0.2 % of the quadrotor-steps, and the multiplier evaluations they need cost 4 % of the launch time)
+    if (const char* t = getenv("MPCQ_PDAS")) m.pdas_max = atoi(t);
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;
     m.h = c.T / c.N; m.dt_pred = c.dt_pred;
     m.finish_r = c.finish_radius > 0 ? c.finish_radius : 1.0;

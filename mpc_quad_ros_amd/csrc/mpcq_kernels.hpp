@@ -41,6 +41,37 @@ namespace mpcq {
 #ifndef MPCQ_F32_TOLS
 #define MPCQ_F32_TOLS 8
 #endif
+// The four Runge-Kutta substages of the shooting / prediction / plant integrators as ONE loop body (rolled) instead of four
+// inlined copies, and the substage loop of the sensitivity pass likewise: the step executes every phase once per control
+// period, so straight-line code is fetched from L2 every time (18 % of the wave cycles waited for instructions with
+// everything unrolled); a loop body is fetched once and then runs from the instruction cache.
+#ifndef MPCQ_ROLL_RK
+#define MPCQ_ROLL_RK 1
+#endif
+#if MPCQ_ROLL_RK
+#define MPCQ_RK_LOOP _Pragma("clang loop unroll(disable)")
+#else
+#define MPCQ_RK_LOOP _Pragma("unroll")
+#endif
+#ifndef MPCQ_ROLL_SENS
+#define MPCQ_ROLL_SENS 1
+#endif
+#if MPCQ_ROLL_SENS
+#define MPCQ_SENS_LOOP _Pragma("clang loop unroll(disable)")
+#else
+#define MPCQ_SENS_LOOP _Pragma("unroll")
+#endif
+// Phases of the step: inlined into the kernel by default; -DMPCQ_NOINLINE_PHASES keeps them as functions so that
+// tools/kernel_resources.sh can attribute the code size (measurement only).  MPCQ_COLD marks the phases only the
+// interior-point fallback uses: out of line, so that the many call sites of the fallback do not each carry a copy.
+#ifdef MPCQ_NOINLINE_PHASES
+#define MPCQ_PHASE __device__ __attribute__((noinline))
+#else
+#define MPCQ_PHASE __device__ inline
+#endif
+#ifndef MPCQ_COLD
+#define MPCQ_COLD __device__ inline
+#endif
 constexpr int NX = 13, NU = 4, NY = 17;
 constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
 constexpr int VS = 16;           // stride of state-sized QP vectors (internal order, 13 used)
@@ -86,6 +117,7 @@ __device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __
 template <typename TQ>
 struct DevModel {
   int N, nb, skip, Tmax, B, qp_max_iter, polish_max, warm_max;
+  int pdas_max;   // passes in which wrong-signed multipliers are released even at an infeasible minimiser (0: primal rule only)
   int gab;   // stage records (AB'', c, qv) live in DevState::stage instead of LDS (must match the kernel instantiation)
   double h, dt_pred;
   double mass, J[3], tmax, xf[4], yf[4], zl[4], g;
@@ -467,22 +499,21 @@ __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const
 
 // one RK4 step of the NOMINAL model in double (quad_optimizer.discrete_dynamics on quad_nominal)
 template <typename M>
-__device__ inline void rk4_nominal(const M& m, const double* x, const double* u, double dt, double* xo) {
+MPCQ_PHASE void rk4_nominal(const M& m, const double* x, const double* u, double dt, double* xo) {
   const QC<double> qc(m);
-  double k1[NX], k2[NX], k3[NX], k4[NX], xt[NX];
+  double k[NX], xt[NX], acc[NX];
   const double* nul = nullptr;
-  model_eval<double, double>(qc, 0, nul, nul, x, u, nul, nul, k1, (double*)nullptr);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) xt[i] = x[i] + dt / 2 * k1[i];
-  model_eval<double, double>(qc, 0, nul, nul, xt, u, nul, nul, k2, (double*)nullptr);
+  for (int i = 0; i < NX; ++i) { xt[i] = x[i]; acc[i] = 0; }
+  MPCQ_RK_LOOP
+  for (int s = 0; s < 4; ++s) {   // k1..k4: acc = k1 + 2 k2 + 2 k3 + k4, next point x + {dt/2, dt/2, dt} k
+    model_eval<double, double>(qc, 0, nul, nul, xt, u, nul, nul, k, (double*)nullptr);
+    const double wa = (s == 0 || s == 3) ? 1.0 : 2.0, hc = s == 2 ? dt : dt / 2;
 #pragma unroll
-  for (int i = 0; i < NX; ++i) xt[i] = x[i] + dt / 2 * k2[i];
-  model_eval<double, double>(qc, 0, nul, nul, xt, u, nul, nul, k3, (double*)nullptr);
+    for (int i = 0; i < NX; ++i) { acc[i] += wa * k[i]; xt[i] = x[i] + hc * k[i]; }
+  }
 #pragma unroll
-  for (int i = 0; i < NX; ++i) xt[i] = x[i] + dt * k3[i];
-  model_eval<double, double>(qc, 0, nul, nul, xt, u, nul, nul, k4, (double*)nullptr);
-#pragma unroll
-  for (int i = 0; i < NX; ++i) xo[i] = x[i] + dt / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+  for (int i = 0; i < NX; ++i) xo[i] = x[i] + dt / 6 * acc[i];
 }
 
 // plant with drag (Quadrotor3D.f_nominal, drag=True, payload=False; src/quad.py:256-381), double
@@ -516,22 +547,21 @@ __device__ inline void plant_eval(const M& m, const double* x, const double* u, 
   f[12] = (m.tmax * tz + (m.J[0] - m.J[1]) * r[0] * r[1]) * m.iJ[2];
 }
 template <typename M>
-__device__ inline void plant_rk4(const M& m, double* x, const double* uin, double dt) {
-  double u[4], k1[NX], k2[NX], k3[NX], k4[NX], xt[NX];
+MPCQ_PHASE void plant_rk4(const M& m, double* x, const double* uin, double dt) {
+  double u[4], k[NX], xt[NX], acc[NX];
 #pragma unroll
   for (int j = 0; j < 4; ++j) u[j] = tmin(1.0, tmax(0.0, uin[j]));
-  plant_eval(m, x, u, k1);
 #pragma unroll
-  for (int i = 0; i < NX; ++i) xt[i] = x[i] + dt / 2 * k1[i];
-  plant_eval(m, xt, u, k2);
+  for (int i = 0; i < NX; ++i) { xt[i] = x[i]; acc[i] = 0; }
+  MPCQ_RK_LOOP
+  for (int s = 0; s < 4; ++s) {
+    plant_eval(m, xt, u, k);
+    const double wa = (s == 0 || s == 3) ? 1.0 : 2.0, hc = s == 2 ? dt : dt / 2;
 #pragma unroll
-  for (int i = 0; i < NX; ++i) xt[i] = x[i] + dt / 2 * k2[i];
-  plant_eval(m, xt, u, k3);
+    for (int i = 0; i < NX; ++i) { acc[i] += wa * k[i]; xt[i] = x[i] + hc * k[i]; }
+  }
 #pragma unroll
-  for (int i = 0; i < NX; ++i) xt[i] = x[i] + dt * k3[i];
-  plant_eval(m, xt, u, k4);
-#pragma unroll
-  for (int i = 0; i < NX; ++i) x[i] = x[i] + dt / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+  for (int i = 0; i < NX; ++i) x[i] = x[i] + dt / 6 * acc[i];
 }
 
 // ------------------------------------------------------------------ kernel configurations
@@ -551,7 +581,7 @@ template <typename C, typename M> __device__ inline int cNB(const M& m) { return
 // pass 1: lane (triple) per interval, 4 RK substages in TQ; writes records + gap c_i = Phi_i - X_{i+1}
 // (the part X_i - X_{i+1} of the gap is formed in double)
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* A, const Lds& L, bool gp) {
+MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* A, const Lds& L, bool gp) {
   const int N = cN<C>(m), lane = lane_id();
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
@@ -570,20 +600,19 @@ __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* 
     for (int j = 0; j < NU; ++j) u[j] = (TQ)D[L.U + i * NU + j];
     const TQ* al = gp ? S + L.alpha : nullptr;
     TQ* sub = (valid && d == 0) ? S + L.sub + i * SUBS : nullptr;
-    model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, x, u, al, S + L.basis, k, sub, gd, gx);
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] = k[j]; xt[j] = x[j] + h / 2 * k[j]; }
-    model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + SUBW : nullptr, gd, gx);
+    for (int j = 0; j < NX; ++j) { acc[j] = 0; xt[j] = x[j]; }
+    MPCQ_RK_LOOP
+    for (int s = 0; s < 4; ++s) {   // acc = k1 + 2 k2 + 2 k3 + k4, next point x + {h/2, h/2, h} k
+      model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + s * SUBW : nullptr, gd, gx);
+      const TQ wa = (s == 0 || s == 3) ? TQ(1) : TQ(2), hc = s == 2 ? h : h / 2;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] += 2 * k[j]; xt[j] = x[j] + h / 2 * k[j]; }
-    model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + 2 * SUBW : nullptr, gd, gx);
-#pragma unroll
-    for (int j = 0; j < NX; ++j) { acc[j] += 2 * k[j]; xt[j] = x[j] + h * k[j]; }
-    model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + 3 * SUBW : nullptr, gd, gx);
+      for (int j = 0; j < NX; ++j) { acc[j] += wa * k[j]; xt[j] = x[j] + hc * k[j]; }
+    }
     if (valid && d == 0) {
 #pragma unroll
       for (int j = 0; j < NX; ++j) {
-        const double gap = (D[L.X + i * NX + j] - D[L.X + (i + 1) * NX + j]) + (double)(h / 6 * (acc[j] + k[j]));
+        const double gap = (D[L.X + i * NX + j] - D[L.X + (i + 1) * NX + j]) + (double)(h / 6 * acc[j]);
         A[L.c + i * VS + o2i(j)] = (TQ)gap;
       }
     }
@@ -591,12 +620,10 @@ __device__ inline void shoot_states(const DevModel<TQ>& m, const double* D, TQ* 
 }
 // pass 2: item = (interval i, column j of [A|B], j = 3..16) -> AB'[i][r][j-3]
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
+MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
   const int N = cN<C>(m);
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
-  const TQ a_s[4] = {TQ(0), TQ(0.5), TQ(0.5), TQ(1)};
-  const TQ w_s[4] = {TQ(1), TQ(2), TQ(2), TQ(1)};
   const TQ c10 = (qc.J[1] - qc.J[2]) * qc.iJ[0], c11 = (qc.J[2] - qc.J[0]) * qc.iJ[1], c12 = (qc.J[0] - qc.J[1]) * qc.iJ[2];
   const TQ tm = qc.tmax * qc.imass;
   for (int it = lane_id(); it < N * 14; it += 64) {
@@ -609,10 +636,10 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds
 #pragma unroll
     for (int c = 0; c < NU; ++c)
       if (j - NX == c) { jur[0] = qc.tmax * qc.yf[c] * qc.iJ[0]; jur[1] = -qc.tmax * qc.xf[c] * qc.iJ[1]; jur[2] = qc.tmax * qc.zl[c] * qc.iJ[2]; }
-#pragma unroll
+    MPCQ_SENS_LOOP
     for (int s = 0; s < 4; ++s) {
       const TQ* sub = S + L.sub + i * SUBS + s * SUBW;
-      const TQ hs = h * a_s[s];
+      const TQ hs = s == 0 ? TQ(0) : (s == 3 ? h : h * TQ(0.5)), ws = (s == 0 || s == 3) ? TQ(1) : TQ(2);
 #pragma unroll
       for (int r = 0; r < NX; ++r) Z[r] = ((r == j) ? TQ(1) : TQ(0)) + hs * Sp[r];
       const TQ qw = sub[3], qx = sub[4], qy = sub[5], qz = sub[6];
@@ -636,7 +663,7 @@ __device__ inline void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds
       Sn[11] = jur[1] + c11 * (r2 * Z[10] + r0 * Z[12]);
       Sn[12] = jur[2] + c12 * (r1 * Z[10] + r0 * Z[11]);
 #pragma unroll
-      for (int r = 0; r < NX; ++r) { acc[r] += w_s[s] * Sn[r]; Sp[r] = Sn[r]; }
+      for (int r = 0; r < NX; ++r) { acc[r] += ws * Sn[r]; Sp[r] = Sn[r]; }
     }
     TQ* AB = A + L.AB + i * ABS;
 #pragma unroll
@@ -675,7 +702,7 @@ __host__ __device__ inline int GI(int i) { return (i >> 2) * VS + 10 + (i & 3); 
 
 // forward rollout dx_{i+1} = A dx_i + B z_i (+ c_i); dx_0 taken from S[dxo + 0..15]
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dxo, int zo, bool with_c) {
+MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dxo, int zo, bool with_c) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[zo + i];
@@ -716,7 +743,7 @@ __device__ inline void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 
 // adjoint sweep: grad = d/dz of the QP objective at (dx(z), z)
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
+MPCQ_COLD void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
@@ -761,7 +788,7 @@ __device__ inline void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 
 // backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, bool polish) {
+MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, bool polish) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
@@ -806,7 +833,7 @@ __device__ inline void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A,
 // affine: the sweep of the affine recursion instead: starts from dx_0 in S[L.dx], adds the gaps (S[L.Dx]) and writes the
 // state trajectory to S[L.dx] (z_i = K_i dx_i + k_i to S[dzo])
 template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
+MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   const Sel<TQ> sel(h);
@@ -885,7 +912,7 @@ __device__ inline void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, cons
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr, TQ* mrows = nullptr,
+MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr, TQ* mrows = nullptr,
                                       TQ* pstore = nullptr, int start = -1) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
@@ -1113,7 +1140,7 @@ __device__ inline bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const
 // vector sweeps.  Continues from the current (z, sl, su, ll, lu, dx, grad) until |r_d| <= tol*gm and
 // mu <= tol.  returns 0 converged / 1 NaN / 2 iteration cap / 4 stage Hessian not positive definite
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
+MPCQ_COLD int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int status = 2;
   const int maxit = m.qp_max_iter;
@@ -1205,7 +1232,7 @@ __device__ inline int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L,
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
     for (int i = tid; i < nv; i += 64) {
@@ -1219,17 +1246,17 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
   __syncthreads();
   TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
   const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
-  bool refactor = true, settled = false;
+  bool settled = false;
   int nact = 1;   // pinned inputs in the working set
   // a bulk release that bounces straight back (the freed inputs violate and get pinned again) makes the next ones
   // more selective: all wrong-signed multipliers -> those within 4x of the worst -> within 1.6x -> the worst only
   int careful = 0;
   bool released = false;
+  unsigned relmask = 0;   // bit k: input tid + 64 k was released in the previous pass (a bounce = it is pinned again in this one)
   int top = N - 1;   // highest stage whose working set changed since the last factorisation (N-1: factorise everything)
   bool keep_p = false;
   for (passes = 0; passes < max_passes; ++passes) {
-    const bool aff = refactor;
-    if (aff) {
+    {
       // New working set.  Its minimiser is the solution of the affine LQ problem with the pinned inputs held at their
       // bounds: their effect B_i zbar_i joins the gap c_i, the stage gradients q_i, r_i enter the vector recursion
       // directly -- ONE masked factorisation and ONE forward sweep, whatever the current point is (no state rollout,
@@ -1243,6 +1270,12 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
         na += a != TQ(0) ? 1 : 0;
       }
       nact = wave_sum(na);
+#ifdef MPCQ_EMU_DEBUG
+      if (passes == 0) {
+        for (int i = tid; i < nv; i += 64)
+          if (S[L.act + i] != TQ(0)) printf("       start: pinned stage %2d rotor %d %s\n", i >> 2, i & 3, S[L.act + i] < 0 ? "lower" : "upper");
+      }
+#endif
       if (passes == 0) {
         // Cost-to-go tiles are kept (43 KB of global stores) only where a change of the working set is likely: some
         // input pinned already, or a free one within `margin` of a bound.  Elsewhere a change (rare) refactorises from
@@ -1269,23 +1302,44 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
       __syncthreads();
       PF_START();
       TQ gfac = 0;
+#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD)
+      pf.acc[13] += (keep_p && top >= 0 && top < N - 1) ? top + 1 : N;   // stages this factorisation visits
+      pf.acc[14] += 1;                                                    // factorisations
+#endif
       const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac, nact > 0 ? G + L.mrow : nullptr, keep_p ? G + L.pst : nullptr, top);
       top = -1;
       PF_STOP(PF_FACTOR);
       if (!fok) return false;
       gm = tmax(gm, tmax(TQ(1), gfac));   // a restarted factorisation sees only the stages it visits
       tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
-      refactor = false;
       PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
       // the sweep returns the minimiser itself: turn it into a step from the current point for the ratio test below
       for (int i = tid; i < nv; i += 64)
         if (S[L.act + i] == TQ(0)) S[L.dz + i] -= S[L.z + i];
       __syncthreads();
-    } else {
-      // the last pass took a full step on an unchanged working set: the point minimises the QP on it (to rounding)
-      if (nact == 0) { settled = true; break; }   // no multipliers to check, the step is exact to rounding
-      // Multipliers of the pinned inputs without a gradient sweep: with the cost-to-go of the factorisation,
-      // lambda_a = gt_a + M_a dx_i + sum_{q free} (B'PB)_aq z_q + R_aa z_a  (rows left behind by riccati_factor)
+    }
+    TQ alpha = 1;
+    int nanf = 0;
+    for (int i = tid; i < nv; i += 64) {
+      if (S[L.act + i] != TQ(0)) continue;
+      const TQ d = S[L.dz + i], z = S[L.z + i];
+      if (!(d == d)) nanf = 1;
+      if (d < 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.lb + i] - z) / d));
+      if (d > 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.ub + i] - z) / d));
+    }
+    alpha = wave_min(alpha);
+    if (wave_max(nanf)) return false;
+    const bool feasible = !(alpha < TQ(1));
+    // Multipliers of the pinned inputs at the minimiser of the working set, without a gradient sweep: with the
+    // cost-to-go of the factorisation, lambda_a = gt_a + M_a dx_i + sum_{q free} (B'PB)_aq z_q + R_aa z_a (rows left
+    // behind by riccati_factor).  A feasible minimiser with correctly signed multipliers is the solution.  Otherwise the
+    // wrong-signed ones are released -- at a feasible minimiser always (the classical primal rule); in the first
+    // `pdas_max` passes, while no release has bounced yet, also when the minimiser violates other bounds (primal-dual
+    // active-set rule: pins and releases in the same pass), which saves one factorisation per release in the cascades
+    // that make the slowest quadrotor of a launch.
+    bool any_release = false;
+    unsigned relnow = 0;
+    if (nact > 0 && (feasible || (passes < m.pdas_max && careful == 0))) {
       TQ vmax = 0;
       for (int i = tid; i < nv; i += 64) {
         const TQ a = S[L.act + i];
@@ -1301,7 +1355,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
           for (int k = 0; k < NX; ++k) lam += rv[k] * S[L.dx + st * VS + k];
 #pragma unroll
           for (int q = 0; q < NU; ++q)
-            if (q != j && S[L.act + st * NU + q] == TQ(0)) lam += rv[NX + q] * S[L.z + st * NU + q];
+            if (q != j && S[L.act + st * NU + q] == TQ(0)) lam += rv[NX + q] * (S[L.z + st * NU + q] + S[L.dz + st * NU + q]);
           vmax = tmax(vmax, a < 0 ? -lam : lam);
         }
         S[L.grad + GI(i)] = lam;
@@ -1309,57 +1363,64 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
       vmax = wave_max(vmax);
       if (!(vmax == vmax)) return false;
 #ifdef MPCQ_EMU_DEBUG
-      if (tid == 0) printf("  polish pass %d warm %d vmax %.3e tolm %.3e nact %d\n", passes, (int)warm, (double)vmax, (double)tolm, nact);
+      if (tid == 0) printf("  polish pass %d warm %d feasible %d vmax %.3e tolm %.3e nact %d\n", passes, (int)warm, (int)feasible, (double)vmax, (double)tolm, nact);
 #endif
-      if (vmax <= tolm) { settled = true; break; }
-      __syncthreads();
-      const TQ rel_thr = careful == 0 ? TQ(0) : (careful == 1 ? TQ(0.25) * vmax : (careful == 2 ? TQ(0.625) * vmax : vmax));
-      int hi = -1;
-      for (int i = tid; i < nv; i += 64) {
-        const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
-        const TQ v = a < 0 ? -g : g;
-        if (a != TQ(0) && v > tolm && v >= rel_thr) { S[L.act + i] = 0; hi = i >> 2; }   // release wrong-signed multipliers
+      if (vmax > tolm) {
+        __syncthreads();
+        const TQ rel_thr = careful == 0 ? TQ(0) : (careful == 1 ? TQ(0.25) * vmax : (careful == 2 ? TQ(0.625) * vmax : vmax));
+        int hi = -1;
+        for (int i = tid; i < nv; i += 64) {
+          const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
+          const TQ v = a < 0 ? -g : g;
+          if (a != TQ(0) && v > tolm && v >= rel_thr) {   // release wrong-signed multipliers (they stay where they are)
+#ifdef MPCQ_EMU_DEBUG
+            printf("       release stage %2d rotor %d %s  multiplier %+.4e\n", i >> 2, i & 3, a < 0 ? "lower" : "upper", (double)g);
+#endif
+            S[L.act + i] = 0; S[L.dz + i] = 0; hi = i >> 2;
+            relnow |= 1u << ((i >> 6) & 31);
+          }
+        }
+        top = tmax(top, wave_max(hi));
+        any_release = true;
       }
-      top = tmax(top, wave_max(hi));
-      refactor = true;
-      released = true;
-      __syncthreads();
-      continue;
     }
-    TQ alpha = 1;
-    int nanf = 0;
-    for (int i = tid; i < nv; i += 64) {
-      if (S[L.act + i] != TQ(0)) continue;
-      const TQ d = S[L.dz + i], z = S[L.z + i];
-      if (!(d == d)) nanf = 1;
-      if (d < 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.lb + i] - z) / d));
-      if (d > 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.ub + i] - z) / d));
-    }
-    alpha = wave_min(alpha);
-    if (wave_max(nanf)) return false;
     // full step; if it leaves the box, clip and pin EVERY violator at once (the minimiser on a working set does not
     // depend on the starting point, so only the sequence of working sets matters)
-    int nblk = 0, hip = -1;
+    int nblk = 0, hip = -1, bounce = 0;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
       const TQ lb = S[L.lb + i], ub = S[L.ub + i];
       TQ z = S[L.z + i] + S[L.dz + i];
-      if (alpha < TQ(1)) {
-        if (z <= lb + tolb) { z = lb; S[L.act + i] = -1; nblk += 1; hip = i >> 2; }
-        else if (z >= ub - tolb) { z = ub; S[L.act + i] = 1; nblk += 1; hip = i >> 2; }
+      if (!feasible) {
+        const bool lo = z <= lb + tolb, up = !lo && z >= ub - tolb;
+        if (lo || up) {
+#ifdef MPCQ_EMU_DEBUG
+          printf("       pin stage %2d rotor %d %s  (unclipped %+.4e, bound %+.4e, had z %+.4e)\n", i >> 2, i & 3, lo ? "lower" : "upper", (double)z, (double)(lo ? lb : ub), (double)S[L.z + i]);
+#endif
+          z = lo ? lb : ub; S[L.act + i] = lo ? TQ(-1) : TQ(1); nblk += 1; hip = i >> 2;
+          bounce |= (relmask >> ((i >> 6) & 31)) & 1u;
+        }
       }
       S[L.z + i] = z;
     }
     nblk = wave_sum(nblk);
+    bounce = wave_max(bounce);
     top = tmax(top, wave_max(hip));
 #ifdef MPCQ_EMU_DEBUG
-    if (tid == 0) printf("     pass %d aff %d alpha %.6e nblk %d\n", passes, (int)aff, (double)alpha, nblk);
+    if (tid == 0) printf("     pass %d alpha %.6e nblk %d release %d\n", passes, (double)alpha, nblk, (int)any_release);
 #endif
+#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD)
+    pf.acc[11] += nblk;                        // inputs pinned
+    pf.acc[12] += any_release ? 1 : 0;         // passes with a release
+    pf.acc[15] += (any_release && nblk > 0) ? 1 : 0;   // passes with both
+#endif
+    if (feasible && !any_release) { settled = true; passes += 1; break; }
     // a bulk release that bounces back wholesale with most of the inputs saturated: far from the optimal working set,
     // the interior point gets there faster
     if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) return false;
-    if (nblk > 0) { refactor = true; if (released && careful < 3) careful += 1; }
-    released = false;
+    if (bounce && careful < 3) careful += 1;   // an input released in the previous pass is pinned again
+    released = any_release;
+    relmask = relnow;
     __syncthreads();
   }
   if (settled && sizeof(TQ) == 4) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
@@ -1372,7 +1433,7 @@ __device__ inline bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const 
 // rollout and a gradient sweep first): used for TQ = float, where increments keep their accuracy while a from-scratch
 // affine solve would have to be refined again every time.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
   bool fresh = false;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
@@ -1534,7 +1595,7 @@ __device__ inline bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, c
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const bool try_warm PF_ARG) {
+MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const bool try_warm PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
@@ -1585,7 +1646,7 @@ __device__ inline int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const
 //   J = k* Kx^-1 ; mu_p = J mu ; Cp = sf2 - J k* + J C J^T ; G = C J^T/(Cp + sn2) ;
 //   mu += G (y - mu_p) ; C -= G (J C)      (not symmetrised, as in the reference)
 template <typename C, typename TQ = typename C::T>
-__device__ inline void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu, TQ* gC, const double* vb, const double* ad, bool c_staged = false) {
+MPCQ_PHASE void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu, TQ* gC, const double* vb, const double* ad, bool c_staged = false) {
   const int n = cNB<C>(m), tid = lane_id(), NT = blockDim.x, n3 = 3 * n, nn = n * n;
   TQ* Cw = S + L.rgp;
   TQ* ks = Cw + al4(3 * nn);

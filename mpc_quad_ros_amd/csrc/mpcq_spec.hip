@@ -12,9 +12,14 @@ namespace mpcq {
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
 
 template <typename T, bool RUN> static StepFn<T> pick(int N, int nb, bool gab) {
+#ifdef MPCQ_RESOURCE_PROBE   // tools/kernel_resources.sh --probe: only the benchmark instance (fp64, global stage records, lockstep)
+  if (N == 20 && nb == 10 && gab && !RUN && sizeof(T) == 8) return (StepFn<T>)&step_kernel<Cfg<double, true, 20, 10, false>>;
+  return nullptr;
+#else
   if (N == 20 && nb == 10)   // BASELINE configs[1]
     return gab ? &step_kernel<Cfg<T, true, 20, 10, RUN>> : &step_kernel<Cfg<T, false, 20, 10, RUN>>;
   return nullptr;
+#endif
 }
 
 // run = the free-running closed-loop variant (mpcq_sim_run)

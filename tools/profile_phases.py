@@ -49,6 +49,10 @@ def main():
     for k, n in FINE.items():
         if mean[k] > 0:
             print(f"  {n:18s} {mean[k]:12.0f}")
+    if mean[14] > 0:   # active-set statistics of the fp64 path (diagnostic counters of polish())
+        tot = acc.sum(axis=0)
+        print(f"factorisations per quad-step {mean[14]:.3f} (slowest quad of a launch: {mxs[14]:.2f}); stages visited per factorisation {tot[13] / tot[14]:.1f}; "
+              f"pins per quad-step {mean[11]:.3f}, passes with a release {mean[12]:.3f}, with both {mean[15]:.3f}")
     other = mean[10] - mean[:10].sum()
     print(f"{'other':10s} {other:12.0f} {100 * other / mean[10]:6.1f}%")
 
