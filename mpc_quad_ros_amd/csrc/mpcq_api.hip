@@ -15,13 +15,25 @@
 #include "../../include/mpcq.h"
 #include "mpcq_kernels.hpp"
 
-namespace mpcq {   // mpcq_spec.hip
+namespace mpcq {   // mpcq_spec.hip, one translation unit per specialised shape
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
-StepFn<double> spec_step_f64(int N, int nb, bool gab, bool run);
-StepFn<float> spec_step_f32(int N, int nb, bool gab, bool run);
+#define MPCQ_SPEC_SHAPES(X) X(20, 10) X(20, 20) X(50, 50)   // BASELINE configs[1] (and [3] per rank), configs[2], configs[4]
+#define MPCQ_DECL(n, nb) StepFn<double> spec_step_f64_##n##_##nb(bool gab, bool run); StepFn<float> spec_step_f32_##n##_##nb(bool gab, bool run);
+MPCQ_SPEC_SHAPES(MPCQ_DECL)
+#undef MPCQ_DECL
 }
-static mpcq::StepFn<double> spec_step(int N, int nb, bool gab, bool run, double*) { return mpcq::spec_step_f64(N, nb, gab, run); }
-static mpcq::StepFn<float> spec_step(int N, int nb, bool gab, bool run, float*) { return mpcq::spec_step_f32(N, nb, gab, run); }
+static mpcq::StepFn<double> spec_step(int N, int nb, bool gab, bool run, double*) {
+#define MPCQ_TRY(n, nb_) if (N == n && nb == nb_) return mpcq::spec_step_f64_##n##_##nb_(gab, run);
+  MPCQ_SPEC_SHAPES(MPCQ_TRY)
+#undef MPCQ_TRY
+  return nullptr;
+}
+static mpcq::StepFn<float> spec_step(int N, int nb, bool gab, bool run, float*) {
+#define MPCQ_TRY(n, nb_) if (N == n && nb == nb_) return mpcq::spec_step_f32_##n##_##nb_(gab, run);
+  MPCQ_SPEC_SHAPES(MPCQ_TRY)
+#undef MPCQ_TRY
+  return nullptr;
+}
 
 namespace {
 

@@ -25,6 +25,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef MPCQ_EMU_DEBUG
+#include <cstdio>
+#endif
 
 namespace mpcq {
 
@@ -237,6 +240,19 @@ template <typename TQ> __host__ __device__ inline size_t lds_bytes(const Lds& L)
 // ------------------------------------------------------------------ small helpers
 template <typename T> struct alignas(16) V4 { T a, b, c, d; };
 
+// Ablation build only (BASELINE configs[4] "fp32 vs bf16 tolerance", csrc/Makefile `variant NAME=bf16`): what is STORED
+// -- the stage records AB'', gaps, cost gradients, and the RGP mean / covariance between steps -- is rounded to bfloat16
+// (8 significant bits, round to nearest even) while the arithmetic stays fp32.  The product never defines MPCQ_BF16_RECORDS.
+#ifdef MPCQ_BF16_RECORDS
+__device__ inline float st16(float v) {
+  unsigned u = (unsigned)__float_as_int(v);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return __int_as_float((int)(u & 0xFFFF0000u));
+}
+__device__ inline double st16(double v) { return v; }   // the fp64 path is not part of that ablation
+#else
+template <typename T> __device__ inline T st16(T v) { return v; }
+#endif
 template <typename T> __device__ inline T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> __device__ inline T tmax(T a, T b) { return a > b ? a : b; }
 
@@ -296,6 +312,7 @@ __host__ __device__ inline int i2o(int k) { return k < 10 ? k + 3 : k - 10; }
 // back as the B operand of the next product (and a symmetric one as the A operand) without leaving
 // registers.  RI differs between the f32 and f64 instructions.
 template <typename TQ> __device__ inline int RI(int s, int h) { return sizeof(TQ) == 4 ? 4 * h + s : h + 4 * s; }
+#ifndef MPCQ_NO_MFMA
 __device__ inline void mfma(float (&acc)[4], float a, float b) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   f4 cc = {acc[0], acc[1], acc[2], acc[3]};
@@ -311,6 +328,21 @@ __device__ inline void mfma(double (&acc)[4], double a, double b) {
 #endif
   acc[0] = cc[0]; acc[1] = cc[1]; acc[2] = cc[2]; acc[3] = cc[3];
 }
+#else
+// Ablation build (BASELINE configs[4] "MFMA on/off", csrc/Makefile `variant NAME=nomfma`): the same tile product with
+// the matrix cores switched off -- operands fetched from the lanes that hold them through the LDS crossbar
+// (ds_bpermute), products on the vector ALU.  D[RI(reg,h)][c] += sum_k A[RI(reg,h)][k] B[k][c], A[r][k] on lane 16k + r,
+// B[k][c] on lane 16k + c.  Same results up to the summation order inside one instruction.
+template <typename T> __device__ inline void mfma(T (&acc)[4], T a, T b) {
+  const int lane = lane_id(), h = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const T bk = __shfl(b, 16 * k + c);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) acc[reg] = fma(__shfl(a, 16 * k + RI<T>(reg, h)), bk, acc[reg]);
+  }
+}
+#endif
 // A state-sized vector rides in column 14 of a tile: lane (h, 14) holds slots RI(s,h), s = 0..3.
 __device__ inline void vl_load(const float* base, int h, float (&v)[4]) {   // slots 4h..4h+3: one 128-bit read
   const V4<float> t = *reinterpret_cast<const V4<float>*>(base + 4 * h);
@@ -613,7 +645,7 @@ MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* 
 #pragma unroll
       for (int j = 0; j < NX; ++j) {
         const double gap = (D[L.X + i * NX + j] - D[L.X + (i + 1) * NX + j]) + (double)(h / 6 * acc[j]);
-        A[L.c + i * VS + o2i(j)] = (TQ)gap;
+        A[L.c + i * VS + o2i(j)] = st16((TQ)gap);
       }
     }
   }
@@ -667,7 +699,7 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
     }
     TQ* AB = A + L.AB + i * ABS;
 #pragma unroll
-    for (int r = 0; r < NX; ++r) AB[o2i(r) * ABW + jp] = ((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r];
+    for (int r = 0; r < NX; ++r) AB[o2i(r) * ABW + jp] = st16(((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r]);
   }
   // zero the two pad columns (read by the vectorised 4-wide loads)
   for (int it = lane_id(); it < N * NX * 2; it += 64) A[L.AB + (it >> 1) * ABW + 14 + (it & 1)] = 0;
@@ -1318,18 +1350,18 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
         if (S[L.act + i] == TQ(0)) S[L.dz + i] -= S[L.z + i];
       __syncthreads();
     }
-    TQ alpha = 1;
-    int nanf = 0;
+    // Does the minimiser of the working set leave the box?  (ratio test of the step from the current feasible point:
+    // alpha < 1  <=>  some free input ends outside its bounds; only that bit is needed, so no divisions)
+    int flags = 0;   // bit 0: a free input violates a bound, bit 1: not a number
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
-      const TQ d = S[L.dz + i], z = S[L.z + i];
-      if (!(d == d)) nanf = 1;
-      if (d < 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.lb + i] - z) / d));
-      if (d > 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.ub + i] - z) / d));
+      const TQ zn = S[L.z + i] + S[L.dz + i];
+      if (!(zn == zn)) flags |= 2;
+      if (zn < S[L.lb + i] || zn > S[L.ub + i]) flags |= 1;
     }
-    alpha = wave_min(alpha);
-    if (wave_max(nanf)) return false;
-    const bool feasible = !(alpha < TQ(1));
+    flags = wave_reduce(flags, [](int a, int b) { return a | b; });
+    if (flags & 2) return false;
+    const bool feasible = !(flags & 1);
     // Multipliers of the pinned inputs at the minimiser of the working set, without a gradient sweep: with the
     // cost-to-go of the factorisation, lambda_a = gt_a + M_a dx_i + sum_{q free} (B'PB)_aq z_q + R_aa z_a (rows left
     // behind by riccati_factor).  A feasible minimiser with correctly signed multipliers is the solution.  Otherwise the
@@ -1367,12 +1399,26 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
 #endif
       if (vmax > tolm) {
         __syncthreads();
-        const TQ rel_thr = careful == 0 ? TQ(0) : (careful == 1 ? TQ(0.25) * vmax : (careful == 2 ? TQ(0.625) * vmax : vmax));
+        // Which of the wrong-signed ones: the multipliers of one rotor's run of saturated stages are strongly coupled
+        // (freeing the input at the end of the run turns the others' signs back), so a bulk release of the whole run is
+        // followed by one re-pinning pass per stage.  Rule: per rotor only the worst multiplier goes (input i belongs to
+        // rotor i & 3 = lane & 3: every lane sees one rotor); after a bounce only the worst one overall.
+        TQ vr = 0;
+        for (int i = tid; i < nv; i += 64) {
+          const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
+          if (a != TQ(0)) vr = tmax(vr, a < 0 ? -g : g);
+        }
+        TQ rel_thr = vmax;
+        if (careful == 0) {
+          const TQ w0 = wave_max((tid & 3) == 0 ? vr : TQ(0)), w1 = wave_max((tid & 3) == 1 ? vr : TQ(0)),
+                   w2 = wave_max((tid & 3) == 2 ? vr : TQ(0)), w3 = wave_max((tid & 3) == 3 ? vr : TQ(0));
+          rel_thr = (tid & 3) == 0 ? w0 : ((tid & 3) == 1 ? w1 : ((tid & 3) == 2 ? w2 : w3));
+        }
         int hi = -1;
         for (int i = tid; i < nv; i += 64) {
           const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
           const TQ v = a < 0 ? -g : g;
-          if (a != TQ(0) && v > tolm && v >= rel_thr) {   // release wrong-signed multipliers (they stay where they are)
+          if (a != TQ(0) && v > tolm && v >= rel_thr) {   // release (they stay where they are)
 #ifdef MPCQ_EMU_DEBUG
             printf("       release stage %2d rotor %d %s  multiplier %+.4e\n", i >> 2, i & 3, a < 0 ? "lower" : "upper", (double)g);
 #endif
@@ -1407,7 +1453,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
     bounce = wave_max(bounce);
     top = tmax(top, wave_max(hip));
 #ifdef MPCQ_EMU_DEBUG
-    if (tid == 0) printf("     pass %d alpha %.6e nblk %d release %d\n", passes, (double)alpha, nblk, (int)any_release);
+    if (tid == 0) printf("     pass %d feasible %d nblk %d release %d\n", passes, (int)feasible, nblk, (int)any_release);
 #endif
 #if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD)
     pf.acc[11] += nblk;                        // inputs pinned
@@ -1690,11 +1736,11 @@ MPCQ_PHASE void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu,
   __syncthreads();
   for (int i = tid; i < n3; i += NT) {
     const int d = i / n;
-    gmu[i] = mu[i] + CJ[i] * sc[d * 4 + 1] * sc[d * 4];
+    gmu[i] = st16(mu[i] + CJ[i] * sc[d * 4 + 1] * sc[d * 4]);
   }
   for (int i = tid; i < 3 * nn; i += NT) {
     const int d = i / nn, r = (i / n) % n, c = i % n;
-    gC[i] = Cw[i] - CJ[d * n + r] * sc[d * 4 + 1] * JC[d * n + c];
+    gC[i] = st16(Cw[i] - CJ[d * n + r] * sc[d * 4 + 1] * JC[d * n + c]);
   }
 }
 
@@ -1802,7 +1848,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
         const int i = it / NX, k = it - i * NX;
         const double q = i < N ? m.h * m.W[k] : m.We[k];
         D[L.X + it] = xv[u];
-        A[L.qv + i * VS + o2i(k)] = (TQ)(q * (xv[u] - rv[u]));
+        A[L.qv + i * VS + o2i(k)] = st16((TQ)(q * (xv[u] - rv[u])));
       }
     }
   }

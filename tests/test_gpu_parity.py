@@ -63,8 +63,9 @@ def test_swarm_closed_loop_config2_shape():
 
 
 def test_long_horizon_config5_shape():
-    # N=50 / nb=50 in f32: the whole working set fits the LDS of a CU
-    worst = pc.case_swarm_closed_loop(make, B=4, N=50, nb=50, K=6, precision=1)
+    # BASELINE configs[4] shape N=50 / nb=50 in f32 (the whole working set fits the LDS of a CU): 64 quadrotors x 60
+    # periods starting 2 s into the references with a cold iterate -> interior-point solves, then working-set changes
+    worst = pc.case_swarm_closed_loop(make, B=64, N=50, nb=50, K=60, precision=1, start=200, min_changes=20)
     print("config-5 shape, f32: worst relative control deviation", worst)
     assert worst < 1e-4
 
@@ -72,18 +73,28 @@ def test_long_horizon_config5_shape():
 def test_long_horizon_config5_shape_f64():
     # in fp64 the stage records (AB'', gaps, cost gradients) of N=50 do not fit LDS next to the QP workspace:
     # the engine places them in global memory by itself
-    worst = pc.case_swarm_closed_loop(make, B=4, N=50, nb=50, K=6)
+    worst = pc.case_swarm_closed_loop(make, B=64, N=50, nb=50, K=60, start=200, min_changes=20)
     print("config-5 shape, f64: worst relative control deviation", worst)
     assert worst < 1e-6
 
 
+def test_config2_shape_against_oracle():
+    # BASELINE configs[2] shape N=20 / nb=20 (specialised instance): same protocol
+    worst = pc.case_swarm_closed_loop(make, B=64, N=20, nb=20, K=60, start=200, min_changes=20)
+    print("config-2 shape, f64: worst relative control deviation", worst)
+    assert worst < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(20, 10, 64, 25), (20, 20, 64, 25), (50, 50, 12, 12)], ids=["N20nb10", "N20nb20", "N50nb50"])
 @pytest.mark.parametrize("precision", [0, 1])
-def test_kernel_variants_agree(precision, monkeypatch):
-    """The four step-kernel variants of one precision (stage records in LDS / global memory, shape-specialised /
-    generic instantiation) are the same algorithm: identical working sets, controls equal to rounding."""
+def test_kernel_variants_agree(precision, shape, monkeypatch):
+    """The four step-kernel variants of one precision (stage records in LDS / global memory, shape-specialised -O3 /
+    any-shape -O2 instantiation) are the same algorithm: identical working sets, controls equal to rounding.  Every
+    shape that has a specialised instance (mpcq_spec.hip: BASELINE configs[1], [2], [4]) is covered."""
+    from mpc_quad_ros_amd import _lib
     from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
     from mpc_quad_ros_amd.trajectories import swarm_trajectories
-    B, N, nb, K = 64, 20, 10, 25
+    N, nb, B, K = shape
     traj, lens = swarm_trajectories(11, 0, B)
     x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
     out = {}
@@ -94,27 +105,37 @@ def test_kernel_variants_agree(precision, monkeypatch):
                 monkeypatch.setenv("MPCQ_GENERIC", "1")
             else:
                 monkeypatch.delenv("MPCQ_GENERIC", raising=False)
-            e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision))
+            try:
+                e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision))
+            except _lib.MpcqError as ex:       # N=50/nb=50 in fp64 does not fit the all-LDS placement
+                assert mem == "lds" and "LDS" in str(ex), ex
+                continue
             e.set_trajectories(traj, lens)
             e.sim_reset(x0)
+            e.sim_steps(150 if N == 20 else 40, 2, 5e-3)      # into the regime where working sets change
             ws = []
             for k in range(K):
                 e.sim_steps(1, 2, 5e-3)
                 assert (e.get_status() == 0).all()
                 ws.append(e.sim_get_state()[1].copy())
             out[(mem, generic)] = np.array(ws)
-    ref = out[("lds", True)]
+            e.close()
+    ref = out[("global", True)]
     tol = 1e-9 if precision == 0 else 2e-4
     for k, v in out.items():
         assert pc.rel_err(v, ref) < tol, (k, pc.rel_err(v, ref))
-    if precision == 0:   # same arithmetic, two instantiations: agreement far below the solver tolerances
+    if precision == 0 and ("lds", True) in out:   # same arithmetic, two instantiations: agreement far below the solver tolerances
         assert pc.rel_err(out[("lds", True)], out[("global", True)]) < 1e-12
         assert pc.rel_err(out[("lds", False)], out[("global", False)]) < 1e-12
 
 
-@pytest.mark.parametrize("name,K", [("log_traj1_v10_a10_gp0.npz", 60), ("log_traj0_v10_a10_gp2.npz", 60)])
+@pytest.mark.parametrize("name,K", [
+    ("log_traj1_v10_a10_gp0.npz", 60), ("log_traj0_v10_a10_gp2.npz", 110), ("log_traj0_v15_a5_gp2.npz", 150),
+    ("log_trajectory_v15_a5_gp2.npz", 80), ("log_traj2_v10_a10_gp2.npz", 100), ("log_traj1_v15_a5_gp2.npz", 45)])
 def test_f32_qp_mode_teacher_forced(name, K):
-    """Fast mode (QP arithmetic in float, state / QP data in double): tolerance 1e-4 relative (north_star)."""
+    """Fast mode (QP arithmetic in float, state / QP data in double) on the same six logs and windows as the fp64 test:
+    tolerance 1e-4 relative control deviation (the north_star budget), at most parity_cases.F32_OUTLIERS_PER_LOG steps per
+    log between 1e-4 and 5e-4 (reported)."""
     worst = pc.case_teacher_forced_log(make, name, K, precision=1, check_rgp=False)
     print(name, "f32 worst relative control deviation", worst)
 
