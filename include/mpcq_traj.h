@@ -1,0 +1,34 @@
+/* mpcq_traj.h — C ABI of libmpcq_traj.so: minimum-snap reference trajectories through waypoints (host code, C++).
+ *
+ * Upstream of the control-step path: the reference writes random waypoints to a CSV and shells out to its
+ * prebuilt `genTrajectory` binary (src/trajectory_generation/TrajectoryGenerator.py:133-191), which returns 7th-order
+ * polynomial segments in the CSV layout of uav_trajectory.Trajectory (src/trajectory_generation/uav_trajectory.py:116-129);
+ * these entry points produce that layout.  Sampling to the 13-state reference stays where the reference has it, in Python
+ * (mpc_quad_ros_amd/trajectories.py: sample_polynomial_trajectory = save_evals_csv + load_trajectory,
+ * TrajectoryGenerator.py:208-244).
+ *
+ * All arrays are caller-owned, C-contiguous float64.  wp [n,3] waypoints (the first is the start point), T [n-1] segment
+ * durations, pieces [n-1,33] rows (duration, x^0..x^7, y^0..y^7, z^0..z^7, yaw^0..yaw^7).  Return 0 on success,
+ * negative on bad arguments (-1), a singular system (-2) or limits that cannot be met (-3).
+ */
+#ifndef MPCQ_TRAJ_H
+#define MPCQ_TRAJ_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ramp estimate of the segment times from distances and the limits --v_max / --a_max of the reference's command line */
+int mpcq_minsnap_estimate_times(const double* wp, int32_t n, double v_max, double a_max, double* T);
+/* minimum-snap polynomials for given times: positions fixed at the waypoints, v / a / jerk continuous at interior
+ * waypoints, zero at both ends */
+int mpcq_minsnap_solve(const double* wp, int32_t n, const double* T, double* pieces);
+/* estimate + solve + uniform time scaling until the sampled peak speed / acceleration meet v_max / a_max */
+int mpcq_minsnap_generate(const double* wp, int32_t n, double v_max, double a_max, double* pieces);
+/* polynomial_representation.csv in the reference's format ("%.6f", header line) */
+int mpcq_minsnap_write_csv(const char* path, const double* pieces, int32_t nseg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCQ_TRAJ_H */

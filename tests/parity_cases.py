@@ -134,7 +134,7 @@ def case_swarm_closed_loop(make_engine, B, N, nb, K, precision=0, seed=1, plant_
     traj, lens = swarm_trajectories(seed, 0, B)
     x = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
     if start:
-        assert lens.min() > start + N * 5
+        assert lens.min() > start + K, lens.min()
         traj, lens = np.ascontiguousarray(traj[:, start:]), lens - start
         x = traj[:, 0].copy()
     e.set_trajectories(traj, lens); o.set_trajectories(traj, lens)
