@@ -25,12 +25,12 @@ def _check(line, n):
     r = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] in ("hbm", "mfma")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert d["value"] > 0 and d["tracking"]["steps"] == d["config"]["global_batch"] * (d["steps"] + d["warmup"])
+    assert d["value"] > 0 and d["tracking"]["steps"] == d["config"]["global_batch"] * (d["steps"] + d["warmup"] + d["config"]["preroll_periods"])
     return d
 
 
 def test_single_rank_line():
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tests", "run_bench_emu.py"), "--steps", "2", "--warmup", "1",
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tests", "run_bench_emu.py"), "--steps", "2", "--warmup", "1", "--preroll", "3",
                                    "--batch", "2", "--horizon", "5", "--nb", "10", "--no-cpu-baseline", "--no-alt"], cwd=ROOT)
     lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -41,7 +41,7 @@ def test_two_ranks_under_torchrun():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "run_bench_emu.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "run_bench_emu.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--preroll", "3",
            "--batch", "2", "--horizon", "5", "--nb", "10"]
     out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=600)
     lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]

@@ -1,13 +1,15 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh TAG'): the bench line, the rocprofv3 kernel
-# trace summary and the PMC passes (each in its own run, kernel-trace only) the numbers in profiles/ come from.
-TAG=${1:-r1_final}
+# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_profiles.sh TAG [bench args]'): the bench line, the rocprofv3 kernel
+# trace summary and the PMC passes (each in its own run, kernel-trace only) the numbers in profiles/ come from.  Every
+# pass runs THE SAME bench command (same pre-roll, warm-up and steps), so kernel time, counters and traffic describe
+# the same launches; the program itself follows `--` (no env / bash -c hop under the profiler).
+TAG=${1:-r2_final}; shift
 O=gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-python3 bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-alt"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py --no-cpu-baseline --no-alt > $O/prof_$TAG.log 2>&1
+ARGS="--no-cpu-baseline --no-alt $@"
+python3 bench.py $@ > $O/bench_$TAG.json 2> $O/bench_$TAG.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS > $O/prof_$TAG.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_${TAG}_fetch -- python3 bench.py $ARGS > $O/pmc_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_${TAG}_write -- python3 bench.py $ARGS > $O/pmc_${TAG}_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_${TAG}_sq -- python3 bench.py $ARGS > $O/pmc_${TAG}_sq.log 2>&1

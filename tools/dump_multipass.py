@@ -12,11 +12,9 @@ from mpc_quad_ros_amd.trajectories import swarm_trajectories
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/multipass_cases.npz"
 min_passes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 B, N, nb = 1024, 20, 10
-e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb)))
-traj, lens = swarm_trajectories(2026, 0, B)
-e.set_trajectories(traj, lens)
-e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
-e.sim_steps(150, 2, 5e-3)
+import bench
+e, _ = bench.make_engine(B, N, nb, 0, 0, 0, 2026)
+e.sim_steps(bench.PREROLL, 2, 5e-3)
 cases = []
 for k in range(120):
     st, sol, x = e.get_state(), e.get_solver_state(), e.sim_get_state()[0]
@@ -24,7 +22,7 @@ for k in range(120):
     it = e.get_qp_iter()
     for b in np.nonzero((it % 1000) >= min_passes)[0][:3]:
         if len(cases) < 60:
-            cases.append(dict(b=b, step=150 + k, passes=it[b], x=x[b], X=st["X"][b], U=st["U"][b], mu=st["mu"][b], C=st["C"][b],
+            cases.append(dict(b=b, step=bench.PREROLL + k, passes=it[b], x=x[b], X=st["X"][b], U=st["U"][b], mu=st["mu"][b], C=st["C"][b],
                               xpp=st["x_pred_prev"][b], hp=st["has_prev"][b], idx=st["idx"][b], qp_iter=sol["qp_iter"][b], w=e.sim_get_state()[1][b]))
 keys = cases[0].keys()
 np.savez_compressed(out, traj_idx=np.array([c["b"] for c in cases]), **{k: np.array([c[k] for c in cases]) for k in keys})

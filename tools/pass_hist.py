@@ -10,11 +10,9 @@ from mpc_quad_ros_amd.trajectories import swarm_trajectories
 prec = 1 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else 0
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 220
 B, N, nb = 1024, 20, 10
-e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=prec))
-traj, lens = swarm_trajectories(2026, 0, B)
-e.set_trajectories(traj, lens)
-e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
-e.sim_steps(int(os.environ.get('PREROLL', '150')), 2, 5e-3)   # same regime as bench.py
+import bench
+e, _ = bench.make_engine(B, N, nb, prec, 0, 0, 2026)        # the bench workload (min-snap references)
+e.sim_steps(int(os.environ.get('PREROLL', bench.PREROLL)), 2, 5e-3)   # same regime as bench.py
 hist = collections.Counter(); permax = []; kt = []
 for k in range(steps):
     e.sim_steps(1, 2, 5e-3)

@@ -22,11 +22,9 @@ def main():
     B, N, nb = 1024, 20, 10
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     lib = os.path.join(ROOT, "mpc_quad_ros_amd", "libmpcq_prof.so")
-    e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=prec), lib_path=lib)
-    traj, lens = swarm_trajectories(2026, 0, B)
-    e.set_trajectories(traj, lens)
-    e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
-    e.sim_steps(int(os.environ.get('PREROLL', '150')), 2, 5e-3)   # same regime as bench.py
+    import bench
+    e, _ = bench.make_engine(B, N, nb, prec, 0, 0, 2026, lib_path=lib)      # the bench workload (min-snap references)
+    e.sim_steps(int(os.environ.get('PREROLL', bench.PREROLL)), 2, 5e-3)   # same regime as bench.py
     acc = np.zeros((B, 16))
     mx = np.zeros(16)
     its = []

@@ -16,7 +16,8 @@ which = [int(a) for a in sys.argv[2:]] or range(len(d["b"]))
 N, nb = 20, 10
 for c in which:
     b = int(d["b"][c])
-    traj, lens = swarm_trajectories(2026, b, 1)
+    import bench
+    traj, lens = swarm_trajectories(2026, b, 1, kind=bench.TRAJECTORY_KIND, v_max=12.0, a_max=12.0)
     e = Engine(EngineConfig(batch=1, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb)), lib_path=lib)
     e.set_trajectories(traj, lens)
     e.set_state(X=d["X"][c][None], U=d["U"][c][None], mu=d["mu"][c][None], C=d["C"][c][None], x_pred_prev=d["xpp"][c][None],
