@@ -249,8 +249,12 @@ struct EngineT : mpcq_engine {
     m.polish_max = f32 ? 12 : 16;   // fp64 passes alternate between a multiplier check and an affine solve: twice the count of fp32's
     if (const char* t = getenv("MPCQ_IPM_TOL")) m.ipm_tol = (T)atof(t);
     if (const char* t = getenv("MPCQ_POLISH_MAX")) m.polish_max = atoi(t);
-    m.warm_max = f32 ? 12 : 24;   // passes of the warm active-set attempt before falling back to the IPM
+    // passes of the warm active-set attempt before falling back to the IPM (fp64: one factorisation each, an interior-point
+    // solve costs about 15 of them; measured on the min-snap bench workload, lockstep: 24 -> 1.14 M steps/s, 10 -> 1.21 M, 6 -> 1.31 M)
+    m.warm_max = f32 ? 12 : 8;
     if (const char* t = getenv("MPCQ_WARM_MAX")) m.warm_max = atoi(t);
+    m.warm_retry = 2;
+    if (const char* t = getenv("MPCQ_WARM_RETRY")) m.warm_retry = atoi(t);
     m.pdas_max = 0;   // passes in which pins and releases may happen together (fp64 active-set method; measured on the bench workload: such passes are rare, 0.2 % of the quadrotor-steps, and the multiplier evaluations they need cost 4 % of the launch time)
     if (const char* t = getenv("MPCQ_PDAS")) m.pdas_max = atoi(t);
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;

@@ -120,6 +120,7 @@ __device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __
 template <typename TQ>
 struct DevModel {
   int N, nb, skip, Tmax, B, qp_max_iter, polish_max, warm_max;
+  int warm_retry; // cap of the warm attempt in the period after one that fell back to the interior point
   int pdas_max;   // passes in which wrong-signed multipliers are released even at an infeasible minimiser (0: primal rule only)
   int gab;   // stage records (AB'', c, qv) live in DevState::stage instead of LDS (must match the kernel instantiation)
   double h, dt_pred;
@@ -1641,13 +1642,19 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const bool try_warm PF_ARG) {
+MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const int prev_iter PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
-  if (try_warm && m.warm_max > 0) {
-    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, m.warm_max PF_PASS)
-                        : polish_incremental<C>(m, S, A, L, gm, wpasses, true, m.warm_max PF_PASS)) {   // sets z = 0 and its own gradient scale
+  // prev_iter: pass count of this quadrotor's previous solve (0: cold start, >= 1000: its warm attempt was given up).  A
+  // quadrotor whose references are out of reach (inputs saturated over most of the horizon, the working set changing by
+  // many inputs every period) fails the warm attempt period after period: after a fallback the next attempt is short
+  // (warm_retry passes), so that such a quadrotor costs its launch one interior-point solve, not that plus a long
+  // active-set attempt; the first period in which the short attempt succeeds restores the full budget.
+  const int warm_cap = prev_iter >= 1000 ? m.warm_retry : m.warm_max;
+  if (prev_iter > 0 && warm_cap > 0) {
+    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap PF_PASS)
+                        : polish_incremental<C>(m, S, A, L, gm, wpasses, true, warm_cap PF_PASS)) {   // sets z = 0 and its own gradient scale
       *status = 0;
       return wpasses;
     }
@@ -1891,7 +1898,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b] > 0 PF_PASS);
+  const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b] PF_PASS);
   PF_START();
   // ---- 3. full step (iterate accumulated in double).  A step that is not finite (a QP that broke down: only seen
   //      with the fp32 QP on infeasible references) is not taken: the iterate and the control of the previous period
