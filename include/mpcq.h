@@ -45,6 +45,12 @@ typedef enum mpcq_status {
 #define MPCQ_SOLVE_MAXITER 2
 #define MPCQ_SOLVE_QP_FAILURE 4
 
+/* mpcq_config.flags.  MPCQ_FLAG_STATIC_GP: the GP in the model is a static one (use_gp = 1, gpe.type == "GP",
+ * src/quad_opt.py:228-236 with src/gp/GP.py:136-175): basis = its training inputs, theta = (L, sigma_f,
+ * sqrt(noise + 1e-7)), the training responses are loaded once with mpcq_set_params and the fused step does NOT
+ * run the recursive update (mean and covariance stay as they are). */
+#define MPCQ_FLAG_STATIC_GP 1
+
 #define MPCQ_PRECISION_F64 0
 #define MPCQ_PRECISION_F32 1
 
@@ -69,7 +75,7 @@ typedef struct mpcq_config {
   int32_t device;        /* HIP device ordinal */
   int32_t precision;     /* MPCQ_PRECISION_* : arithmetic type of the device path */
   int32_t qp_max_iter;   /* 0 = default */
-  int32_t reserved;
+  int32_t flags;         /* MPCQ_FLAG_* */
   double finish_radius;  /* EPSILON_TRAJECTORY_FINISHED [m], src/mpc_controller_node.py:118; 0 = default 1.0 */
 } mpcq_config;
 
@@ -198,6 +204,20 @@ int mpcq_set_state(mpcq_engine* e, const double* X, const double* U, const doubl
  * finished flags [B].  With mpcq_get_state + mpcq_sim_get_state a restored engine continues bit for bit. */
 int mpcq_get_solver_state(mpcq_engine* e, int32_t* qp_iter, double* stats, int32_t* finished);
 int mpcq_set_solver_state(mpcq_engine* e, const int32_t* qp_iter, const double* stats, const int32_t* finished);
+
+/* ---- RGP.learn (src/gp/RGP.py:332-505), SURVEY §8 f4: hyper-parameter learning of the recursive GP (unscented
+ * transform over eta = (L, sigma_f, sigma_n) + Kalman / smoother updates) for batch x 3 independent (quadrotor, axis)
+ * regressors on the device, fp64.  The loop body never calls learn in the reference (offline estimator), so this is an
+ * object of its own: basis [3, nb] and theta [3, 3] as in mpcq_config (initial values, shared by the batch), nb <= 64.
+ * mpcq_learn_step feeds one sample per regressor: v_body [B,3] (inputs), a_drag [B,3] (targets).  mpcq_learn_get:
+ * mu_g [B,3,nb], C_g [B,3,nb,nb], mu_eta [B,3,3], C_eta [B,3,3,3], Kx_inv [B,3,nb,nb] (K_x^-1 rebuilt for the new
+ * hyper-parameters, RGP.py:499-500); any pointer may be NULL.  Errors: mpcq_learn_last_error(). */
+typedef struct mpcq_learner mpcq_learner;
+const char* mpcq_learn_last_error(void);
+int mpcq_learn_create(int32_t batch, int32_t nb, const double* basis, const double* theta, int32_t device, mpcq_learner** out);
+int mpcq_learn_destroy(mpcq_learner* l);
+int mpcq_learn_step(mpcq_learner* l, const double* v_body, const double* a_drag);
+int mpcq_learn_get(mpcq_learner* l, double* mu_g, double* C_g, double* mu_eta, double* C_eta, double* Kx_inv);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,11 @@ SYMBOLS = [
     ("mpcq_set_state", ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
     ("mpcq_get_solver_state", ctypes.c_int, [_vp, _ip, _dp, _ip]),
     ("mpcq_set_solver_state", ctypes.c_int, [_vp, _ip, _dp, _ip]),
+    ("mpcq_learn_last_error", ctypes.c_char_p, []),
+    ("mpcq_learn_create", ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _dp, _dp, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    ("mpcq_learn_destroy", ctypes.c_int, [_vp]),
+    ("mpcq_learn_step", ctypes.c_int, [_vp, _dp, _dp]),
+    ("mpcq_learn_get", ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp]),
 ]
 
 

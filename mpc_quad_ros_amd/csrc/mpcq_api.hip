@@ -402,6 +402,7 @@ struct EngineT : mpcq_engine {
   }
   int set_params(const double* mu) override { return nb ? h2q(st.mu, mu, (size_t)B * 3 * nb) : 0; }
 
+  int base_mode() const { return (cfg.flags & MPCQ_FLAG_STATIC_GP) ? mpcq::MODE_STATIC_GP : 0; }
   int launch_step(int mode) {
     HIP_TRY(hipEventRecord(ev0, stream));
     hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, st, mode);
@@ -474,7 +475,7 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipMemcpyAsync(d_xin, h_pin, nx * sizeof(double), hipMemcpyHostToDevice, stream));
     st.x_meas = d_xin;
     int rc;
-    if ((rc = launch_step(mpcq::MODE_TRAJ | mpcq::MODE_POST))) return rc;
+    if ((rc = launch_step(mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode()))) return rc;
     HIP_TRY(hipMemcpyAsync(h_pin + nx, st.w, nw * sizeof(double), hipMemcpyDeviceToHost, stream));
     if (x_pred_out) HIP_TRY(hipMemcpyAsync(h_pin + nx + nw, st.xpred, nx * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -488,7 +489,7 @@ struct EngineT : mpcq_engine {
     s2.x_meas = d_x;
     if (d_w) s2.w = d_w;
     HIP_TRY(hipEventRecord(ev0, stream));
-    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST);
+    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
@@ -513,7 +514,7 @@ struct EngineT : mpcq_engine {
     s2.run_x = d_xs; s2.run_steps = 1; s2.run_nsub = n_sub; s2.run_dt = sim_dt;
     for (int k = 0; k < K; ++k) {
       const bool timed_launch = k % stride == 0;
-      const int mode = mpcq::MODE_TRAJ | mpcq::MODE_POST | ((!split && k > 0) ? mpcq::MODE_PLANT_FIRST : 0);
+      const int mode = mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode() | ((!split && k > 0) ? mpcq::MODE_PLANT_FIRST : 0);
       if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride)], stream));
       hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mode);
       if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride) + 1], stream));
@@ -544,7 +545,7 @@ struct EngineT : mpcq_engine {
     while ((int)kev.size() < 2) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
     HIP_TRY(hipEventRecord(ev0, stream));
     HIP_TRY(hipEventRecord(kev[0], stream));
-    hipLaunchKernelGGL(krun, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST | mpcq::MODE_RUN);
+    hipLaunchKernelGGL(krun, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST | mpcq::MODE_RUN | base_mode());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(kev[1], stream));
     HIP_TRY(hipEventRecord(ev1, stream));

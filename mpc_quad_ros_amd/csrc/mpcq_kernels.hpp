@@ -85,7 +85,8 @@ constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded 
 constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
 constexpr int SUBS = 4 * SUBW + 1;  // per-stage stride of the records (odd: lanes of different stages hit different banks)
 
-enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4, MODE_PLANT_FIRST = 8 };
+enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4, MODE_PLANT_FIRST = 8, MODE_STATIC_GP = 16 };
+// MODE_STATIC_GP: the GP of the model is fixed (mpcq_config.flags & MPCQ_FLAG_STATIC_GP): the post phase skips the RGP update.
 // MODE_RUN: free-running closed loop, DevState::run_* periods per launch.  MODE_PLANT_FIRST: the launch starts by
 // advancing the plant state run_x with the previous launch's control (lockstep closed loop without a plant kernel
 // between two step launches: the integration overlaps the global loads of the load phase).
@@ -1403,17 +1404,18 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
         // Which of the wrong-signed ones: the multipliers of one rotor's run of saturated stages are strongly coupled
         // (freeing the input at the end of the run turns the others' signs back), so a bulk release of the whole run is
         // followed by one re-pinning pass per stage.  Rule: per rotor only the worst multiplier goes (input i belongs to
-        // rotor i & 3 = lane & 3: every lane sees one rotor); after a bounce only the worst one overall.
+        // rotor i & 3 = lane & 3: every lane sees one rotor); after bounces fewer rotors, in the end only the worst one overall.
         TQ vr = 0;
         for (int i = tid; i < nv; i += 64) {
           const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
           if (a != TQ(0)) vr = tmax(vr, a < 0 ? -g : g);
         }
-        TQ rel_thr = vmax;
-        if (careful == 0) {
+        TQ rel_thr = vmax;   // careful == 3: the worst one overall (the classical rule)
+        if (careful < 3) {   // per rotor the worst one; after bounces only rotors whose worst is within 4x / 1.6x of the overall worst
           const TQ w0 = wave_max((tid & 3) == 0 ? vr : TQ(0)), w1 = wave_max((tid & 3) == 1 ? vr : TQ(0)),
                    w2 = wave_max((tid & 3) == 2 ? vr : TQ(0)), w3 = wave_max((tid & 3) == 3 ? vr : TQ(0));
           rel_thr = (tid & 3) == 0 ? w0 : ((tid & 3) == 1 ? w1 : ((tid & 3) == 2 ? w2 : w3));
+          rel_thr = tmax(rel_thr, careful == 0 ? TQ(0) : (careful == 1 ? TQ(0.25) * vmax : TQ(0.625) * vmax));
         }
         int hi = -1;
         for (int i = tid; i < nv; i += 64) {
@@ -1958,7 +1960,8 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   if (mode & MODE_POST) {
   // ---- 4. post: nominal prediction, cursor, drag estimate, RGP regress, statistics
   double* vbad = D + L.x0 + NX;   // [v_body(3), a_drag(3)]
-  if (gp) {   // stage the covariance while lane 0 integrates the nominal model (QP workspace is dead)
+  const bool regress = gp && !(mode & MODE_STATIC_GP);
+  if (regress) {   // stage the covariance while lane 0 integrates the nominal model (QP workspace is dead)
     const TQ* gC = st.C + (size_t)b * 3 * nb * nb;
     for (int i = tid; i < 3 * nb * nb; i += 64) S[L.rgp + i] = gC[i];
   }
@@ -2002,7 +2005,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     if ((mode & MODE_TRAJ) && idx + 2 == len && sqrt(ep) < m.finish_r) st.finished[b] = 1;
   }
   __syncthreads();
-  if (gp) rgp_regress<C>(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3, true);
+  if (regress) rgp_regress<C>(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3, true);
   }
   if (C::RUN) {   // the plant produces the next measurement (plant_kernel of the lockstep path)
     if (tid == 0) {

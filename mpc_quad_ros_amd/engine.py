@@ -235,3 +235,46 @@ class Engine:
         out = np.zeros(5)
         self._check(self.lib.mpcq_allreduce_tracking_stats(self.h, _lib.d(out)))
         return out
+
+
+class Learner:
+    """batch x 3 recursive GPs with hyper-parameter learning on the device (RGP.learn, src/gp/RGP.py:332-505);
+    the offline estimator of the reference, not part of the control step."""
+
+    def __init__(self, batch, basis, theta, device=0, lib_path=None):
+        self.lib = _lib.load(lib_path)
+        self.basis = np.ascontiguousarray(basis, dtype=np.float64).reshape(3, -1)
+        th = np.asarray(theta, dtype=np.float64)
+        self.theta = np.ascontiguousarray(np.tile(th, (3, 1)) if th.shape == (3,) else th.reshape(3, 3))
+        self.B, self.nb = int(batch), self.basis.shape[1]
+        h = ctypes.c_void_p()
+        self._check(self.lib.mpcq_learn_create(self.B, self.nb, _lib.d(self.basis), _lib.d(self.theta), int(device), ctypes.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.MpcqError(f"mpcq error {rc}: {self.lib.mpcq_learn_last_error().decode()}")
+
+    def step(self, v_body, a_drag):
+        s = np.ascontiguousarray(v_body, dtype=np.float64).reshape(self.B, 3)
+        y = np.ascontiguousarray(a_drag, dtype=np.float64).reshape(self.B, 3)
+        self._check(self.lib.mpcq_learn_step(self.h, _lib.d(s), _lib.d(y)))
+
+    def get(self):
+        B, n = self.B, self.nb
+        out = dict(mu_g=np.zeros((B, 3, n)), C_g=np.zeros((B, 3, n, n)), mu_eta=np.zeros((B, 3, 3)), C_eta=np.zeros((B, 3, 3, 3)),
+                   K_x_inv=np.zeros((B, 3, n, n)))
+        self._check(self.lib.mpcq_learn_get(self.h, _lib.d(out["mu_g"]), _lib.d(out["C_g"]), _lib.d(out["mu_eta"]), _lib.d(out["C_eta"]),
+                                            _lib.d(out["K_x_inv"])))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mpcq_learn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -82,7 +82,7 @@ class CConfig(ctypes.Structure):
         ("basis", ctypes.POINTER(ctypes.c_double)), ("theta", ctypes.POINTER(ctypes.c_double)),
         # --- product-only tail (the oracle's struct ends above)
         ("device", ctypes.c_int32), ("precision", ctypes.c_int32),
-        ("qp_max_iter", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("qp_max_iter", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("finish_radius", ctypes.c_double),
     ]
 
@@ -112,6 +112,7 @@ class EngineConfig:
     device: int = 0
     precision: int = PRECISION_F64
     qp_max_iter: int = 0              # 0 -> implementation default
+    static_gp: bool = False           # MPCQ_FLAG_STATIC_GP: fixed GP in the model (use_gp = 1), no recursive update in the step
     finish_radius: float = 0.0        # EPSILON_TRAJECTORY_FINISHED [m]; 0 -> 1.0 (src/mpc_controller_node.py:118)
 
     def __post_init__(self):
@@ -153,9 +154,18 @@ class EngineConfig:
         self._theta_buf = np.ascontiguousarray(self.theta.ravel(), dtype=np.float64)
         c.basis = self._basis_buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         c.theta = self._theta_buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-        c.device, c.precision, c.qp_max_iter, c.reserved = self.device, self.precision, self.qp_max_iter, 0
+        c.device, c.precision, c.qp_max_iter, c.flags = self.device, self.precision, self.qp_max_iter, (1 if self.static_gp else 0)
         c.finish_radius = float(self.finish_radius)
         return c
+
+
+def static_gp_theta(theta):
+    """Hyper-parameters of a static GP (src/gp/GP.py:113-130: K + (noise + 1e-7) I with noise = theta[-1], NOT squared) in
+    the engine's convention K_x = K + sigma_n^2 I: [L, sigma_f, sqrt(noise + 1e-7)]."""
+    th = np.asarray(theta, dtype=np.float64)
+    if th.ndim == 1:
+        return np.array([th[0], th[-2], np.sqrt(th[-1] + 1e-7)])
+    return np.stack([static_gp_theta(t) for t in th])
 
 
 def rgp_basis_linspace(v_max: float, nb: int) -> np.ndarray:

@@ -725,6 +725,144 @@ int plant_control_period(const Model& m, double* x, const double* u, double cont
   return n;
 }
 
+
+// ---------------------------------------------------------------- RGP.learn (src/gp/RGP.py:332-505)
+// Hyper-parameter learning of the recursive GP: joint state z = [g (n), eta = (L, sigma_f, sigma_n)], one scalar
+// observation (Xt, yt) per call; unscented transform over eta (7 sigma points, w0 = 0.5), Kalman update of the observable
+// part [sigma_n, g_t], smoother-type update of the rest, then K_x and K_x^-1 are rebuilt from the new hyper-parameters.
+// Restated operation by operation, including what the reference does NOT do: the gain Jt is evaluated once at the current
+// hyper-parameters (not per sigma point), the cross-covariance C_g_eta is never updated (stays zero, so St = 0), and the
+// running mean is used inside the covariance accumulation loop.  The loop of the node never calls it (offline use).
+struct Learner {
+  int n = 0;
+  std::vector<double> X, mu_g, C_g, Kxinv;
+  double mu_eta[3], C_eta[9];
+};
+// principal square root of a symmetric positive definite 3x3 matrix (scipy.linalg.sqrtm of n/(1-w0) C): Jacobi rotations
+void sqrtm3(const double* A, double* S) {
+  double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  std::copy(A, A + 9, a);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p * 3 + q] == 0.0) continue;
+        const double th = (a[q * 3 + q] - a[p * 3 + p]) / (2 * a[p * 3 + q]);
+        const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1));
+        const double c = 1 / std::sqrt(t * t + 1), sn = t * c;
+        for (int k = 0; k < 3; ++k) { const double akp = a[k * 3 + p], akq = a[k * 3 + q]; a[k * 3 + p] = c * akp - sn * akq; a[k * 3 + q] = sn * akp + c * akq; }
+        for (int k = 0; k < 3; ++k) { const double apk = a[p * 3 + k], aqk = a[q * 3 + k]; a[p * 3 + k] = c * apk - sn * aqk; a[q * 3 + k] = sn * apk + c * aqk; }
+        for (int k = 0; k < 3; ++k) { const double vkp = v[k * 3 + p], vkq = v[k * 3 + q]; v[k * 3 + p] = c * vkp - sn * vkq; v[k * 3 + q] = sn * vkp + c * vkq; }
+      }
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double t = 0;
+      for (int k = 0; k < 3; ++k) t += v[i * 3 + k] * std::sqrt(a[k * 3 + k]) * v[j * 3 + k];
+      S[i * 3 + j] = t;
+    }
+}
+void learner_rebuild(Learner& g) {   // K_x = K(X,X) + sigma_n^2 I ; K_x^-1  (:499-500)
+  const int n = g.n;
+  std::vector<double> K((size_t)n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) K[i * n + j] = rbf(g.X[i], g.X[j], g.mu_eta[0], g.mu_eta[1]) + (i == j ? g.mu_eta[2] * g.mu_eta[2] : 0.0);
+  invert(K, n, g.Kxinv);
+}
+void learner_init(Learner& g, int n, const double* X, const double* theta) {   // RGP.__init__ (:126-157)
+  g.n = n;
+  g.X.assign(X, X + n);
+  g.mu_g.assign(n, 0.0);
+  for (int k = 0; k < 3; ++k) g.mu_eta[k] = theta[k];
+  for (int k = 0; k < 9; ++k) g.C_eta[k] = (k % 4 == 0) ? 1.0 : 0.0;
+  g.C_g.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) g.C_g[i * n + j] = rbf(X[i], X[j], theta[0], theta[1]) + (i == j ? theta[2] * theta[2] : 0.0);
+  learner_rebuild(g);
+}
+void learner_step(Learner& g, double xt, double yt) {
+  const int n = g.n, np_ = n + 4, nu = n + 2;
+  const double L = g.mu_eta[0], sf = g.mu_eta[1];
+  std::vector<double> ks(n), Jt(n), CJ(n);
+  for (int j = 0; j < n; ++j) ks[j] = rbf(xt, g.X[j], L, sf);
+  for (int j = 0; j < n; ++j) { double t = 0; for (int i = 0; i < n; ++i) t += ks[i] * g.Kxinv[i * n + j]; Jt[j] = t; }
+  double Jk = 0;
+  for (int j = 0; j < n; ++j) Jk += Jt[j] * ks[j];
+  const double Bv = rbf(xt, xt, L, sf) - Jk;
+  // sigma points of eta
+  double S6[9], C6[9], Sq[9], w[7], eh[7][3];
+  for (int k = 0; k < 9; ++k) C6[k] = 3.0 / (1 - 0.5) * g.C_eta[k];
+  sqrtm3(C6, Sq);
+  (void)S6;
+  w[0] = 0.5;
+  for (int k = 0; k < 3; ++k) eh[0][k] = g.mu_eta[k];
+  for (int i = 0; i < 3; ++i) {
+    for (int k = 0; k < 3; ++k) { eh[i + 1][k] = g.mu_eta[k] + Sq[k * 3 + i]; eh[i + 4][k] = g.mu_eta[k] - Sq[k * 3 + i]; }
+    w[i + 1] = w[i + 4] = (1 - w[0]) / 6.0;
+  }
+  // C_p_i (the same for every sigma point): [[Cg, 0, Cg Jt'], [0, 0, 0], [Jt Cg, 0, Jt Cg Jt' + B]]
+  std::vector<double> Cpi((size_t)np_ * np_, 0.0), mu_p(np_, 0.0), C_p((size_t)np_ * np_, 0.0), mpi(np_), JC(n);
+  double JCJ = 0, Jmu = 0;
+  for (int i = 0; i < n; ++i) { double t = 0; for (int j = 0; j < n; ++j) t += g.C_g[i * n + j] * Jt[j]; CJ[i] = t; }
+  for (int j = 0; j < n; ++j) { double t = 0; for (int i = 0; i < n; ++i) t += Jt[i] * g.C_g[i * n + j]; JC[j] = t; }
+  for (int j = 0; j < n; ++j) { JCJ += JC[j] * Jt[j]; Jmu += Jt[j] * g.mu_g[j]; }
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) Cpi[i * np_ + j] = g.C_g[i * n + j];
+    Cpi[i * np_ + n + 3] = CJ[i];
+    Cpi[(n + 3) * np_ + i] = JC[i];
+  }
+  Cpi[(n + 3) * np_ + n + 3] = JCJ + Bv;
+  for (int i = 0; i < 7; ++i) {
+    for (int k = 0; k < n; ++k) mpi[k] = g.mu_g[k];
+    for (int k = 0; k < 3; ++k) mpi[n + k] = eh[i][k];
+    mpi[n + 3] = Jmu;
+    for (int k = 0; k < np_; ++k) mu_p[k] += w[i] * mpi[k];
+    for (int a = 0; a < np_; ++a)
+      for (int b = 0; b < np_; ++b) C_p[a * np_ + b] += w[i] * ((mpi[a] - mu_p[a]) * (mpi[b] - mu_p[b]) + Cpi[a * np_ + b]);
+  }
+  // observable o = [sigma_n, g_t] = indices nu, nu+1 ; unobservable u = [g, L, sigma_f] = indices < nu
+  const double mo0 = mu_p[nu], mo1 = mu_p[nu + 1];
+  const double Co00 = C_p[nu * np_ + nu], Co01 = C_p[nu * np_ + nu + 1], Co10 = C_p[(nu + 1) * np_ + nu], Co11 = C_p[(nu + 1) * np_ + nu + 1];
+  const double Cy = Co11 + Co00 + mo0 * mo0;
+  const double G0 = Co01 / Cy, G1 = Co11 / Cy;
+  const double me0 = mo0 + G0 * (yt - mo1), me1 = mo1 + G1 * (yt - mo1);
+  const double Ce00 = Co00 - G0 * Cy * G0, Ce01 = Co01 - G0 * Cy * G1, Ce10 = Co10 - G1 * Cy * G0, Ce11 = Co11 - G1 * Cy * G1;
+  const double det = Co00 * Co11 - Co01 * Co10;
+  const double Ci00 = Co11 / det, Ci01 = -Co01 / det, Ci10 = -Co10 / det, Ci11 = Co00 / det;
+  std::vector<double> Lt((size_t)nu * 2);
+  for (int a = 0; a < nu; ++a) {   // Lt = C_ou' inv(C_o): C_ou[k][a] = C_p[(nu+k)][a]
+    const double c0 = C_p[nu * np_ + a], c1 = C_p[(nu + 1) * np_ + a];
+    Lt[a * 2] = c0 * Ci00 + c1 * Ci10;
+    Lt[a * 2 + 1] = c0 * Ci01 + c1 * Ci11;
+  }
+  const double D00 = Ce00 - Co00, D01 = Ce01 - Co01, D10 = Ce10 - Co10, D11 = Ce11 - Co11;
+  std::vector<double> mu_z(n + 3), C_z((size_t)(n + 3) * (n + 3));
+  for (int a = 0; a < nu; ++a) mu_z[a] = mu_p[a] + Lt[a * 2] * (me0 - mo0) + Lt[a * 2 + 1] * (me1 - mo1);
+  mu_z[nu] = me0;
+  const int nz = n + 3;
+  for (int a = 0; a < nu; ++a)
+    for (int b = 0; b < nu; ++b) {
+      const double t0 = Lt[a * 2] * D00 + Lt[a * 2 + 1] * D10, t1 = Lt[a * 2] * D01 + Lt[a * 2 + 1] * D11;
+      C_z[a * nz + b] = C_p[a * np_ + b] + t0 * Lt[b * 2] + t1 * Lt[b * 2 + 1];
+    }
+  for (int a = 0; a < nu; ++a) {
+    C_z[a * nz + nu] = Lt[a * 2] * Ce00 + Lt[a * 2 + 1] * Ce10;   // Lt C_e h
+    C_z[nu * nz + a] = Ce00 * Lt[a * 2] + Ce01 * Lt[a * 2 + 1];   // h' C_e Lt'
+  }
+  C_z[nu * nz + nu] = Ce00;
+  for (int i = 0; i < n; ++i) {
+    g.mu_g[i] = mu_z[i];
+    for (int j = 0; j < n; ++j) g.C_g[i * n + j] = C_z[i * nz + j];
+  }
+  for (int a = 0; a < 3; ++a) {
+    g.mu_eta[a] = mu_z[n + a];
+    for (int b = 0; b < 3; ++b) g.C_eta[a * 3 + b] = C_z[(n + a) * nz + n + b];
+  }
+  learner_rebuild(g);
+}
+struct LearnBatch { int B = 0, n = 0; std::vector<Learner> g; };   // [B][3]
+
 // ---------------------------------------------------------------- batched engine (state + fused step)
 struct Engine {
   Model m;
@@ -736,6 +874,7 @@ struct Engine {
   int Tmax = 0;
   std::vector<double> yref, yrefN;  // [B][N][17], [B][13]
   std::vector<double> stats;        // [B][4]: sum e_pos^2, sum e_vel^2, steps, max e_pos^2
+  bool static_gp = false;           // use_gp = 1: the GP of the model is fixed (src/quad_opt.py:228-236), no regress in the loop
 };
 
 void engine_reset(Engine& e) {
@@ -963,7 +1102,7 @@ void orc_step(void* h, const double* x_meas, double* w_out, double* x_pred_out) 
       for (int k = 0; k < 3; ++k) e2 += (x[k] - chunk[k]) * (x[k] - chunk[k]);
       if (e.idx[b] + 1 == e.tlen[b] && std::sqrt(e2) < 1.0) e.finished[b] = 1;
     }
-    if (n) {
+    if (n && !e.static_gp) {
       const double* xpm1 = e.has_prev[b] ? &e.xpred_prev[(size_t)b * NX] : x;
       double vb[3], ad[3];
       compute_a_drag(x, xpm1, m.dt_pred, vb, ad);
@@ -1032,6 +1171,36 @@ int orc_set_threads(int n) {
   (void)n;
   return 1;
 #endif
+}
+
+// use_gp = 1 (static GP in the model, src/quad_opt.py:228-236): the fused step keeps mu = the training responses fixed
+void orc_set_static_gp(void* h, int on) { ((Engine*)h)->static_gp = on != 0; }
+
+// RGP.learn for B x 3 independent recursive GPs (src/gp/RGP.py:332-505): basis [3*n], theta [9] shared initial values
+void* orc_learn_create(int B, int n, const double* basis, const double* theta) {
+  LearnBatch* l = new LearnBatch();
+  l->B = B; l->n = n; l->g.resize((size_t)B * 3);
+  for (int b = 0; b < B; ++b)
+    for (int d = 0; d < 3; ++d) learner_init(l->g[(size_t)b * 3 + d], n, basis + d * n, theta + d * 3);
+  return l;
+}
+void orc_learn_destroy(void* h) { delete (LearnBatch*)h; }
+void orc_learn_step(void* h, const double* s, const double* y) {
+  LearnBatch& l = *(LearnBatch*)h;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < l.B * 3; ++i) learner_step(l.g[i], s[i], y[i]);
+}
+void orc_learn_get(void* h, double* mu_g, double* C_g, double* mu_eta, double* C_eta, double* Kxinv) {
+  LearnBatch& l = *(LearnBatch*)h;
+  const int n = l.n;
+  for (int i = 0; i < l.B * 3; ++i) {
+    const Learner& g = l.g[i];
+    if (mu_g) std::copy(g.mu_g.begin(), g.mu_g.end(), mu_g + (size_t)i * n);
+    if (C_g) std::copy(g.C_g.begin(), g.C_g.end(), C_g + (size_t)i * n * n);
+    if (mu_eta) std::copy(g.mu_eta, g.mu_eta + 3, mu_eta + (size_t)i * 3);
+    if (C_eta) std::copy(g.C_eta, g.C_eta + 9, C_eta + (size_t)i * 9);
+    if (Kxinv) std::copy(g.Kxinv.begin(), g.Kxinv.end(), Kxinv + (size_t)i * n * n);
+  }
 }
 
 }  // extern "C"

@@ -51,6 +51,12 @@ def load(native: bool = False):
         lib.orc_plant_control_period.restype = ctypes.c_int
         lib.orc_set_threads.restype = ctypes.c_int
         lib.orc_set_threads.argtypes = [ctypes.c_int]
+        lib.orc_learn_create.restype = ctypes.c_void_p
+        lib.orc_learn_create.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp]
+        lib.orc_learn_destroy.argtypes = [ctypes.c_void_p]
+        lib.orc_learn_step.argtypes = [ctypes.c_void_p, _dp, _dp]
+        lib.orc_learn_get.argtypes = [ctypes.c_void_p, _dp, _dp, _dp, _dp, _dp]
+        lib.orc_set_static_gp.argtypes = [ctypes.c_void_p, ctypes.c_int]
         _libs[native] = lib
     return _libs[native]
 
@@ -188,6 +194,10 @@ class OracleEngine:
         self.lib.orc_get_command(self.h, _d(rotor), _d(coll), _d(rates))
         return rotor, coll, rates
 
+    def set_static_gp(self, on=True):
+        """use_gp = 1: the GP in the model is fixed (mu = training responses via set_params), no regress in the loop."""
+        self.lib.orc_set_static_gp(self.h, int(bool(on)))
+
     def set_threads(self, n):
         return self.lib.orc_set_threads(int(n))
 
@@ -227,6 +237,41 @@ class OracleEngine:
         AB = np.zeros((NX, NY))
         self.lib.orc_rk4_sens(self.h, _d(x), _d(u), _d(mu), ctypes.c_double(h), _d(phi), _d(AB))
         return phi, AB
+
+
+class OracleLearner:
+    """B x 3 recursive GPs with hyper-parameter learning (RGP.learn, src/gp/RGP.py:332-505), fp64 CPU restatement."""
+
+    def __init__(self, batch, basis, theta):
+        self.lib = load()
+        self.basis = np.ascontiguousarray(basis, dtype=np.float64).reshape(3, -1)
+        th = np.asarray(theta, dtype=np.float64)
+        self.theta = np.ascontiguousarray(np.tile(th, (3, 1)) if th.shape == (3,) else th.reshape(3, 3))
+        self.B, self.nb = batch, self.basis.shape[1]
+        self.h = ctypes.c_void_p(self.lib.orc_learn_create(batch, self.nb, _d(self.basis), _d(self.theta)))
+
+    def step(self, s, y):
+        s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.B, 3)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(self.B, 3)
+        self.lib.orc_learn_step(self.h, _d(s), _d(y))
+
+    def get(self):
+        B, n = self.B, self.nb
+        out = dict(mu_g=np.zeros((B, 3, n)), C_g=np.zeros((B, 3, n, n)), mu_eta=np.zeros((B, 3, 3)), C_eta=np.zeros((B, 3, 3, 3)),
+                   K_x_inv=np.zeros((B, 3, n, n)))
+        self.lib.orc_learn_get(self.h, _d(out["mu_g"]), _d(out["C_g"]), _d(out["mu_eta"]), _d(out["C_eta"]), _d(out["K_x_inv"]))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.orc_learn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def compute_a_drag(x, x_pred_minus_1, dt):

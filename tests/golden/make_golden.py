@@ -10,6 +10,8 @@ box except the .npz files it writes, which hold data only:
                      These are outputs of the real acados+HPIPM+numpy reference.
 * rgp_vectors.npz  — input/output vectors produced by importing the reference's src/gp/RGP.py
                      (casadi stubbed: only its numpy path is executed) on seeded random streams.
+* learn_vectors.npz— RGP.learn (hyper-parameter UKF) streams, gp_vectors.npz — static GP posterior means (src/gp/GP.py), both
+                     produced the same way.
 * utils_vectors.npz— outputs of the reference's get_reference_chunk / compute_a_drag
                      (src/utils/utils.py:897-950; the module itself cannot be imported because of
                      dead imports at :22,:29,:30, so the needed function definitions are
@@ -86,6 +88,7 @@ def import_reference_rgp():
         pass
 
     cs.MX = MX
+    cs.Function = type("Function", (), {})   # only named in annotations of src/gp/GP.py
     sys.modules["casadi"] = cs
     if not hasattr(np, "NaN"):
         np.NaN = np.nan  # src/gp/RGP.py:92 predates numpy 2
@@ -123,6 +126,55 @@ def make_rgp_vectors():
     out["ncases"] = len(cases)
     np.savez_compressed(os.path.join(OUT, "rgp_vectors.npz"), **out)
     print("wrote rgp_vectors.npz")
+
+
+def make_learn_vectors():
+    """RGP.learn (src/gp/RGP.py:332-505) on seeded streams: per step the joint mean / covariance it returns, the
+    hyper-parameter estimate and the rebuilt K_x^-1."""
+    ref = import_reference_rgp()
+    rng = np.random.default_rng(20261003)
+    out = {}
+    cases = [(10, [1.0, 0.1, 0.1], 12.0, 30), (20, [1.0, 1.0, 0.1], 10.0, 20), (10, [3.0, 0.5, 0.05], 15.0, 30)]
+    for ci, (nb, theta, vmax, K) in enumerate(cases):
+        X = np.linspace(-vmax, vmax, nb)
+        g = ref.RGP(X, np.zeros(nb), theta=list(theta))
+        s = rng.uniform(-vmax, vmax, K)
+        y = 0.3 * s + 0.02 * s * np.abs(s) + rng.normal(0, 0.1, K)
+        mu_z, C_z, kxi = [], [], []
+        for k in range(K):
+            m, C = g.learn(np.array([s[k]]), np.array([y[k]]))
+            mu_z.append(np.real(np.array(m, dtype=np.complex128)).copy())
+            C_z.append(np.real(np.array(C, dtype=np.complex128)).copy())
+            kxi.append(np.array(g.K_x_inv, dtype=np.float64).copy())
+        p = f"c{ci}_"
+        out[p + "nb"] = nb; out[p + "theta"] = np.array(theta); out[p + "X"] = X
+        out[p + "s"] = s; out[p + "y"] = y
+        out[p + "mu_z"] = np.array(mu_z); out[p + "C_z"] = np.array(C_z)[[0, K // 2, K - 1]]; out[p + "C_z_steps"] = np.array([0, K // 2, K - 1])
+        out[p + "K_x_inv_last"] = kxi[-1]
+    out["ncases"] = len(cases)
+    np.savez_compressed(os.path.join(OUT, "learn_vectors.npz"), **out)
+    print("wrote learn_vectors.npz")
+
+
+def make_gp_vectors():
+    """Static GP of the use_gp = 1 model path (src/gp/GP.py:76-175): posterior mean at a few points for fixed training data."""
+    import_reference_rgp()          # installs the casadi stub
+    sys.path.insert(0, os.path.join(REF, "src", "gp"))
+    import GP as ref_gp  # noqa
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = [(12, [1.0, 1.0, 0.1]), (20, [2.0, 0.5, 0.01]), (8, [0.7, 2.0, 0.3])]
+    for ci, (n, theta) in enumerate(cases):
+        X = np.sort(rng.uniform(-10, 10, n))
+        y = 0.3 * X + 0.02 * X * np.abs(X) + rng.normal(0, 0.05, n)
+        g = ref_gp.GP(X, y, theta=list(theta))
+        xs = rng.uniform(-11, 11, 16)
+        mean = np.array([np.ravel(g.predict(np.array([v])))[0] for v in xs], dtype=np.float64)
+        p = f"c{ci}_"
+        out[p + "X"] = X; out[p + "y"] = y; out[p + "theta"] = np.array(theta); out[p + "xs"] = xs; out[p + "mean"] = mean
+    out["ncases"] = len(cases)
+    np.savez_compressed(os.path.join(OUT, "gp_vectors.npz"), **out)
+    print("wrote gp_vectors.npz")
 
 
 def extract_utils_functions(names):
@@ -226,4 +278,6 @@ if __name__ == "__main__":
     make_circle_vectors()
     make_logs()
     make_rgp_vectors()
+    make_learn_vectors()
+    make_gp_vectors()
     make_utils_vectors()

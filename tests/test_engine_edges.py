@@ -246,8 +246,79 @@ def _checkpoint_resume_is_bitwise(lib):
     assert np.array_equal(a.get_tracking_stats(), b.get_tracking_stats())
 
 
+def _rgp_learn_matches_reference_streams(lib):
+    """f4: batched RGP.learn on the device (mpcq_learn_*) against the vectors produced by importing the reference's
+    RGP.py (tests/golden/learn_vectors.npz) and against the CPU restatement on a batch of different streams."""
+    from helpers import load_golden
+    from mpc_quad_ros_amd.engine import Learner
+    from oracle.oracle import OracleLearner
+    v = load_golden("learn_vectors.npz")
+    for c in range(int(v["ncases"])):
+        p = f"c{c}_"
+        nb, X, theta = int(v[p + "nb"]), v[p + "X"], v[p + "theta"]
+        lr = Learner(2, np.tile(X, (3, 1)), theta, lib_path=lib)
+        s, y = v[p + "s"], v[p + "y"]
+        for k in range(len(s)):
+            lr.step(np.full((2, 3), s[k]), np.full((2, 3), y[k]))
+            g = lr.get()
+            mu_z = np.concatenate([g["mu_g"][1, 2], g["mu_eta"][1, 2]])
+            assert np.abs(mu_z - v[p + "mu_z"][k]).max() < 1e-8 * max(1.0, np.abs(v[p + "mu_z"][k]).max()), (c, k)
+        Cz, Ki = v[p + "C_z"][-1], v[p + "K_x_inv_last"]
+        assert np.abs(g["C_g"][0, 0] - Cz[:nb, :nb]).max() < 1e-8 * max(1.0, np.abs(Cz).max())
+        assert np.abs(g["C_eta"][0, 0] - Cz[nb:, nb:]).max() < 1e-8 * max(1.0, np.abs(Cz).max())
+        assert np.abs(g["K_x_inv"][1, 1] - Ki).max() < 1e-7 * np.abs(Ki).max()
+        lr.close()
+    # a batch of different streams per regressor against the CPU restatement
+    rng = np.random.default_rng(3)
+    B, nb = 5, 12
+    basis = np.tile(np.linspace(-12, 12, nb), (3, 1))
+    theta = np.array([[1.0, 0.1, 0.1], [2.0, 0.5, 0.05], [1.5, 0.3, 0.2]])
+    a, o = Learner(B, basis, theta, lib_path=lib), OracleLearner(B, basis, theta)
+    for k in range(12):
+        sv = rng.uniform(-10, 10, (B, 3)); yv = 0.3 * sv + rng.normal(0, 0.1, (B, 3))
+        a.step(sv, yv); o.step(sv, yv)
+    ga, go = a.get(), o.get()
+    for key in ga:
+        assert np.abs(ga[key] - go[key]).max() < 1e-8 * max(1.0, np.abs(go[key]).max()), key
+    with pytest.raises(_lib.MpcqError):
+        Learner(1, np.zeros((3, 65)), [1.0, 0.1, 0.1], lib_path=lib)
+
+
+def _static_gp_model_path(lib):
+    """use_gp = 1: static GP in the model (flag MPCQ_FLAG_STATIC_GP): training inputs as basis, responses loaded with
+    set_params, no recursive update in the fused step; against the oracle in the same mode."""
+    from helpers import load_golden
+    from mpc_quad_ros_amd.params import static_gp_theta
+    v = load_golden("gp_vectors.npz")
+    X, y, theta = v["c0_X"], v["c0_y"], v["c0_theta"]
+    n, B, N = len(X), 3, 10
+    kw = dict(batch=B, N=N, quad=hummingbird(), nb=n, basis=np.tile(X, (3, 1)), theta=static_gp_theta(theta))
+    e = Engine(EngineConfig(static_gp=True, **kw), lib_path=lib)
+    o = OracleEngine(EngineConfig(**kw)); o.set_static_gp(True)
+    mu = np.tile(np.tile(y, 3), (B, 1))
+    traj = np.zeros((B, 60, 13)); traj[:, :, 3] = 1.0; traj[:, :, 2] = 3.0
+    traj[:, :, 0] = np.linspace(0, 4, 60)[None, :] * np.array([1.0, 1.5, 2.0])[:, None]
+    traj[:, :, 7] = (4 / 0.59) * np.array([1.0, 1.5, 2.0])[:, None]
+    for eng in (e, o):
+        eng.set_trajectories(traj); eng.set_params(mu)
+    x = traj[:, 0].copy()
+    for k in range(8):
+        w, xp = e.step(x); wo, xpo = o.step(x)
+        assert np.abs(w - wo).max() < 1e-8 and (e.get_status() == 0).all()
+        x = o.plant_control_period(x, wo, 0.01, 5e-3)[0]
+    mu_e, C_e = e.get_rgp(); mu_o, C_o = o.get_rgp()
+    assert np.array_equal(mu_e.reshape(B, -1), mu) and np.array_equal(mu_o.reshape(B, -1), mu)      # untouched by the loop
+    Kx, _ = o.get_kx()
+    assert np.abs(C_e[0] - Kx).max() < 1e-12
+    # the same engine without the flag does update
+    e2 = Engine(EngineConfig(**kw), lib_path=lib)
+    e2.set_trajectories(traj); e2.set_params(mu); e2.step(traj[:, 0].copy())
+    assert not np.array_equal(e2.get_rgp()[0].reshape(B, -1), mu)
+
+
 CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log, _free_running_equals_lockstep,
-         _command_and_finished, _chunk_cases_on_device, _plant_period_matches_reference_logs, _checkpoint_resume_is_bitwise]
+         _command_and_finished, _chunk_cases_on_device, _plant_period_matches_reference_logs, _checkpoint_resume_is_bitwise,
+         _rgp_learn_matches_reference_streams, _static_gp_model_path]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.__name__.strip("_") for c in CASES])

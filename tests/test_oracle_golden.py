@@ -189,3 +189,53 @@ def test_qp_solution_satisfies_kkt():
         assert U.min() >= 0.0 and U.max() <= 1.0
         nact += int(((U == 0.0) | (U == 1.0)).sum())
     assert nact > 0     # the window really exercises active bounds
+
+
+def test_rgp_learn_against_imported_reference():
+    """RGP.learn (hyper-parameter UKF, src/gp/RGP.py:332-505): the restatement against streams produced by importing the
+    reference (tests/golden/make_golden.py: make_learn_vectors): joint mean every step, joint covariance at three steps,
+    the rebuilt K_x^-1 at the end."""
+    from oracle.oracle import OracleLearner
+    v = load_golden("learn_vectors.npz")
+    for c in range(int(v["ncases"])):
+        p = f"c{c}_"
+        nb, X, theta = int(v[p + "nb"]), v[p + "X"], v[p + "theta"]
+        lr = OracleLearner(1, np.tile(X, (3, 1)), theta)
+        s, y = v[p + "s"], v[p + "y"]
+        csteps = {int(k): i for i, k in enumerate(v[p + "C_z_steps"])}
+        for k in range(len(s)):
+            lr.step(np.full((1, 3), s[k]), np.full((1, 3), y[k]))
+            g = lr.get()
+            mu_z = np.concatenate([g["mu_g"][0, 1], g["mu_eta"][0, 1]])
+            assert np.abs(mu_z - v[p + "mu_z"][k]).max() < 1e-9 * max(1.0, np.abs(v[p + "mu_z"][k]).max()), (c, k)
+            if k in csteps:
+                Cz = v[p + "C_z"][csteps[k]]
+                assert np.abs(g["C_g"][0, 1] - Cz[:nb, :nb]).max() < 1e-9 * max(1.0, np.abs(Cz).max())
+                assert np.abs(g["C_eta"][0, 1] - Cz[nb:, nb:]).max() < 1e-9 * max(1.0, np.abs(Cz).max())
+        Ki = v[p + "K_x_inv_last"]
+        assert np.abs(g["K_x_inv"][0, 2] - Ki).max() < 1e-8 * np.abs(Ki).max()
+        assert np.array_equal(g["mu_g"][0, 0], g["mu_g"][0, 2])        # the three axes received the same stream
+
+
+def test_static_gp_model_matches_reference_gp_predict():
+    """use_gp = 1: the static GP of the model (src/gp/GP.py:76-175) is the RGP-shaped model term with basis = training
+    inputs, mu = training responses and K_x = K + (noise + 1e-7) I, i.e. sigma_n = sqrt(noise + 1e-7)
+    (mpc_quad_ros_amd.params.static_gp_theta).  Posterior means against vectors from the imported reference GP."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, static_gp_theta
+    v = load_golden("gp_vectors.npz")
+    for c in range(int(v["ncases"])):
+        p = f"c{c}_"
+        X, y, theta, xs, mean = v[p + "X"], v[p + "y"], v[p + "theta"], v[p + "xs"], v[p + "mean"]
+        n = len(X)
+        cfg = EngineConfig(batch=1, N=5, quad=hummingbird(), nb=n, basis=np.tile(X, (3, 1)), theta=static_gp_theta(theta))
+        o = OracleEngine(cfg)
+        Kx, Kxi = o.get_kx()
+        alpha = Kxi[0] @ y
+        L, sf = theta[0], theta[1]
+        pred = np.array([np.sum(alpha * sf ** 2 * np.exp(-0.5 * (s - X) ** 2 / L ** 2)) for s in xs])
+        assert np.abs(pred - mean).max() < 1e-9 * max(1.0, np.abs(mean).max())
+        # and through the model itself: vdot gains R m(v_body) with identity attitude
+        x = np.zeros(13); x[3] = 1.0; x[7:10] = xs[:3]
+        f1, _ = o.model_f(x, np.full(4, 0.3), np.tile(y, 3))
+        f0, _ = o.model_f(x, np.full(4, 0.3), np.zeros(3 * n))
+        assert np.abs((f1 - f0)[7:10] - mean[:3]).max() < 1e-9 * max(1.0, np.abs(mean).max())

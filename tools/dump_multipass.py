@@ -20,7 +20,8 @@ for k in range(120):
     st, sol, x = e.get_state(), e.get_solver_state(), e.sim_get_state()[0]
     e.sim_steps(1, 2, 5e-3)
     it = e.get_qp_iter()
-    for b in np.nonzero((it % 1000) >= min_passes)[0][:3]:
+    sel = (it >= 1000) if min_passes >= 1000 else ((it % 1000) >= min_passes)     # min_passes >= 1000: the solves that fell back
+    for b in np.nonzero(sel)[0][:3]:
         if len(cases) < 60:
             cases.append(dict(b=b, step=bench.PREROLL + k, passes=it[b], x=x[b], X=st["X"][b], U=st["U"][b], mu=st["mu"][b], C=st["C"][b],
                               xpp=st["x_pred_prev"][b], hp=st["has_prev"][b], idx=st["idx"][b], qp_iter=sol["qp_iter"][b], w=e.sim_get_state()[1][b]))
