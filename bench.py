@@ -93,10 +93,20 @@ def cpu_baseline(N, nb, seed, budget_s=18.0):
         OracleEngine(EngineConfig(batch=1, N=5), native=True).close()
     except Exception:
         native = False
-    sweep = sorted({1, max(1, min(phys, logical)), logical})
+    quota = None
+    try:      # cgroup v2 CPU quota of the container ("max 100000" = unlimited)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = logical
+    sweep = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, phys, logical) if 1 <= t <= min(logical, affinity)})
     runs = []
     for threads in sweep:
-        B = max(32, 8 * threads)
+        B = max(32, 4 * threads)
         cfg = EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb),
                            theta=[1.0, 0.1, 0.1], dt_pred=0.01)
         o = OracleEngine(cfg, native=native)
@@ -125,7 +135,8 @@ def cpu_baseline(N, nb, seed, budget_s=18.0):
                       f"(dense condensing + IPM, per-thread workspaces), OpenMP {best['threads']} threads, "
                       f"{'-march=native' if native else 'generic'} build",
             "single_thread_steps_per_s": runs[0]["steps_per_s"], "us_per_step_per_thread": best["us_per_step_per_thread"],
-            "host": {"logical_cpus": logical, "physical_cores": phys}, "sweep": runs}
+            "host": {"logical_cpus": logical, "physical_cores": phys, "affinity_cpus": affinity, "cgroup_cpu_quota": quota},
+            "sweep": runs}
 
 
 def call_with_timeout(fn, seconds=90.0):
@@ -301,8 +312,8 @@ def main():
             out["roofline"]["traffic_source"] = t.get("source")
             if args.precision == "f64":
                 out["roofline"]["traffic_note"] = ("fp64 keeps the per-stage records (38.6 KB per instance) in global memory, streamed through L2, so "
-                                                   "that 4 instead of 2 instances fit a CU: ~8x the algorithmic bytes at 0.15 ms per launch; "
-                                                   "the all-LDS placement (MPCQ_STAGE_MEM=lds) moves 15 MB and takes 0.27 ms")
+                                                   "that 4 instead of 2 instances fit a CU; every further working set / interior-point iteration of a "
+                                                   "quadrotor re-reads them, so the traffic grows with the pass count of the launch (DESIGN.md section 3.1)")
         if world == 1 and not args.no_alt:
             # Same K periods as ONE launch in which every quadrotor runs through its periods without waiting for the
             # slowest member of the batch (mpcq_sim_run): the lockstep figure above is what a controller fed by live
@@ -336,8 +347,11 @@ def main():
             k2, l2 = e2.get_kernel_time()
             out["alt_precision"] = {"dtype": alt, "value": B * args.steps / (tb - ta), "unit": "control steps/s",
                                     "kernel_avg_ms": 1e3 * k2 / max(l2, 1),
-                                    "note": "same workload with the QP arithmetic in the other precision (f32: parity ~1e-5 typical / 1e-4 worst, "
-                                            "all-LDS working set; f64: parity ~1e-10, stage records in global memory; both 4 quadrotors per CU)"}
+                                    "note": "same workload with the QP arithmetic in the other precision.  f32 (all-LDS working set): relative control "
+                                            "deviation vs the fp64 oracle <= 1e-4 on every warm-started solve of the six reference logs (median 2e-6); "
+                                            "interior-point fallback solves reach 1e-4..2.2e-4 on three logs and 1.9e-2 on one tumbling step "
+                                            "(profiles/r2_f32_log_report.json, DESIGN.md section 5).  f64 (stage records in global memory): <= 3e-10.  "
+                                            "Both place 4 quadrotors per CU"}
             e2.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, nb, args.seed)

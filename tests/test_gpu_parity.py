@@ -136,8 +136,8 @@ def test_kernel_variants_agree(precision, shape, monkeypatch):
     ("log_trajectory_v15_a5_gp2.npz", 80), ("log_traj2_v10_a10_gp2.npz", 100), ("log_traj1_v15_a5_gp2.npz", 45)])
 def test_f32_qp_mode_teacher_forced(name, K):
     """Fast mode (QP arithmetic in float, state / QP data in double) on the same six logs and windows as the fp64 test:
-    tolerance 1e-4 relative control deviation (the north_star budget), at most parity_cases.F32_OUTLIERS_PER_LOG steps per
-    log between 1e-4 and 5e-4 (reported)."""
+    tolerance 1e-4 relative control deviation (the north_star budget) on every warm-started solve; interior-point fallback
+    solves may exceed it within parity_cases.F32_LOG_BUDGET (three logs, reported)."""
     worst = pc.case_teacher_forced_log(make, name, K, precision=1, check_rgp=False)
     print(name, "f32 worst relative control deviation", worst)
 
