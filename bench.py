@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 from mpc_quad_ros_amd.engine import Engine  # noqa: E402
 from mpc_quad_ros_amd.params import PRECISION_F32, PRECISION_F64, EngineConfig, hummingbird, rgp_basis_linspace  # noqa: E402
-from mpc_quad_ros_amd.trajectories import swarm_trajectories  # noqa: E402
+from mpc_quad_ros_amd.trajectories import swarm_missions  # noqa: E402
 
 X0 = np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0])
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -49,15 +49,21 @@ def algorithmic_flops(N, nb, passes):
     return shoot + passes * (fact + vec) + 24 * nb * nb
 
 
-TRAJECTORY_KIND = "minsnap"   # the reference's trajectory family: min-snap 7th-order polynomials through 3 random waypoints
-PREROLL = 100                 # un-timed control periods before the warm-up (see --preroll)
+PREROLL = 600                 # un-timed control periods before the warm-up (see --preroll)
 
 
-def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None):
+def workload(seed, first_index, B, periods):
+    """Continuous operation of the node, per quadrotor: min-snap flights through 3 random waypoints (v_max = a_max = 12, the
+    launch defaults), each requested from the end point of the previous one (mpc_quad_ros_amd.trajectories.minsnap_mission),
+    long enough for `periods` control periods plus one horizon."""
+    return swarm_missions(seed, first_index, B, periods + 150, v_max=12.0, a_max=12.0)
+
+
+def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None, periods=1000):
     cfg = EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb),
                        theta=[1.0, 0.1, 0.1], dt_pred=0.01, device=device, precision=precision)
     e = Engine(cfg, lib_path=lib_path)
-    traj, lens = swarm_trajectories(seed, first_index, B, kind=TRAJECTORY_KIND, v_max=12.0, a_max=12.0)
+    traj, lens = workload(seed, first_index, B, periods)
     e.set_trajectories(traj, lens)
     e.sim_reset(np.tile(X0, (B, 1)))
     return e, cfg
@@ -111,7 +117,7 @@ def cpu_baseline(N, nb, seed, budget_s=18.0):
                            theta=[1.0, 0.1, 0.1], dt_pred=0.01)
         o = OracleEngine(cfg, native=native)
         o.set_threads(threads)
-        traj, lens = swarm_trajectories(seed, 0, B, kind=TRAJECTORY_KIND, v_max=12.0, a_max=12.0)
+        traj, lens = workload(seed, 0, B, 500)
         o.set_trajectories(traj, lens)
         x = np.tile(X0, (B, 1))
         for _ in range(2):
@@ -175,8 +181,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preroll", type=int, default=PREROLL,
                     help="un-timed control periods before the warm-up, the same for every --steps/--warmup: the timed region "
-                         "always starts in the same regime of the references (1 s into min-snap flights of 2.6 - 9.8 s, median 5.5 s: "
-                         "working sets change on ~5 %% of the quadrotor-steps), not in the hover transient of the first periods")
+                         "starts in the stationary mix of a swarm in continuous operation (each quadrotor chains min-snap flights of "
+                         "2.6 - 9.8 s; after 6 s their phases are spread), whatever --steps and --warmup are")
     ap.add_argument("--strict-rccl", action="store_true", help="exit non-zero when WORLD_SIZE > 1 and the RCCL reduction did not run")
     args = ap.parse_args()
 
@@ -193,7 +199,8 @@ def main():
     B, N, nb = args.batch, args.horizon, args.nb
     prec = PRECISION_F64 if args.precision == "f64" else PRECISION_F32
     itemsize = 8 if prec == PRECISION_F64 else 4
-    e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed)
+    periods = args.preroll + args.warmup + args.steps
+    e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods)
     stats_reduce = "single"
     rccl_hung = False
     if world > 1:
@@ -281,7 +288,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] per GPU: batch {B} hummingbird quadrotors, N={N}, RGP {nb} basis pts/axis, "
-                                   "closed loop with on-device drag plant, seeded random-waypoint min-snap references (3 waypoints, v_max=a_max=12)",
+                                   "closed loop with on-device drag plant, continuous operation on seeded random-waypoint min-snap flights (3 waypoints each, v_max=a_max=12)",
                        "batch_per_gpu": B, "global_batch": B * world, "horizon_nodes": N, "rgp_basis": nb, "preroll_periods": args.preroll,
                        "parallelism": f"shard{world}" if world > 1 else "single", "threads_per_quad": 64,
                        "stats_reduce": stats_reduce, "rccl_ok": world == 1 or stats_reduce == "rccl"},
@@ -320,7 +327,7 @@ def main():
             # measurements gets per tick, this one is the capacity of the device as a closed-loop swarm simulator.
             x_lock, w_lock = e.sim_get_state()
             e.close()
-            e3, _ = make_engine(B, N, nb, prec, local_rank, 0, args.seed)
+            e3, _ = make_engine(B, N, nb, prec, local_rank, 0, args.seed, periods=periods)
             e3.sim_run(args.preroll + args.warmup, n_sub, 5e-3)
             e3.lib.mpcq_synchronize(e3.h)
             ta = time.perf_counter()
@@ -337,7 +344,7 @@ def main():
                                            "slowest instance of the batch"}
             e3.close()
             alt = "f32" if args.precision == "f64" else "f64"
-            e2, _ = make_engine(B, N, nb, PRECISION_F32 if alt == "f32" else PRECISION_F64, local_rank, 0, args.seed)
+            e2, _ = make_engine(B, N, nb, PRECISION_F32 if alt == "f32" else PRECISION_F64, local_rank, 0, args.seed, periods=periods)
             e2.sim_steps(args.preroll + args.warmup, n_sub, 5e-3)
             e2.lib.mpcq_synchronize(e2.h)
             ta = time.perf_counter()

@@ -211,7 +211,7 @@ int mpcq_minsnap_generate(const double* wp, int32_t n, double v_max, double a_ma
   while (violation(hi) > 1.0) { hi *= 1.6; if (hi > 1e3) return -3; }
   if (violation(lo) <= 1.0) hi = lo;
   else
-    for (int it = 0; it < 40 && hi - lo > 1e-6 * hi; ++it) {
+    for (int it = 0; it < 40 && hi - lo > 1e-4 * hi; ++it) {
       const double mid = 0.5 * (lo + hi);
       if (violation(mid) > 1.0) lo = mid; else hi = mid;
     }

@@ -84,7 +84,8 @@ def random_waypoint_trajectory(seed: int, index: int, v_max: float = 12.0, a_max
 def random_waypoints(seed: int, index: int, num_waypoints: int = 3, hsize=(5.0, 5.0, 5.0), start=HOVER):
     """Start point + num_waypoints uniform in the cube (generate_random_waypoints, TrajectoryGenerator.py:133-163);
     the same draws as random_waypoint_trajectory(seed, index)."""
-    rng = np.random.default_rng([int(seed), int(index)])
+    key = [int(s) for s in np.atleast_1d(seed)] + [int(index)]
+    rng = np.random.default_rng(key)
     hs = np.asarray(hsize, dtype=float)
     centre = np.array([0.0, 0.0, 1.5 * hs[2]])
     return np.array([np.asarray(start, dtype=float)] + [rng.uniform(-hs, hs) + centre for _ in range(num_waypoints)])
@@ -158,6 +159,42 @@ def minsnap_trajectory(seed: int, index: int, v_max: float = 12.0, a_max: float 
     """The node's 'random' request through the min-snap generator: x_ref [T, 13] sampled every dt."""
     pieces = minsnap_pieces(random_waypoints(seed, index, **kw), v_max, a_max)
     return sample_polynomial_trajectory_fast(pieces, dt)[0]
+
+
+def minsnap_mission(seed: int, index: int, min_samples: int, v_max: float = 12.0, a_max: float = 12.0, dt: float = 0.01, **kw):
+    """Continuous operation of the node: when a trajectory is finished the next random one is requested from where the
+    quadrotor stands (src/mpc_controller_node.py:374-399, request_trajectory(x, type)).  A mission is that chain of min-snap
+    flights, each through 3 fresh random waypoints starting at the end point of the previous one, until at least
+    min_samples reference rows exist.  Depends only on (seed, index)."""
+    rows, start, leg, n = [], np.asarray(kw.pop("start", HOVER), dtype=float), 0, 0
+    while n < min_samples:
+        wp = random_waypoints([int(seed), 7919 * (leg + 1)], index, start=start, **kw)
+        x = sample_polynomial_trajectory_fast(minsnap_pieces(wp, v_max, a_max), dt)[0]
+        rows.append(x)
+        n += len(x)
+        start, leg = wp[-1], leg + 1
+    return np.concatenate(rows)
+
+
+def _mission_job(args):
+    return minsnap_mission(*args[0], **args[1])
+
+
+def swarm_missions(seed: int, first_index: int, count: int, min_samples: int, **kw):
+    """Padded batch of missions (see minsnap_mission): (traj [count, Tmax, 13], lengths [count]); generated on all host cores."""
+    jobs = [((seed, first_index + i, min_samples), kw) for i in range(count)]
+    if count >= 256:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(mp.cpu_count(), 32)) as pool:
+            trajs = pool.map(_mission_job, jobs, chunksize=max(1, count // 256))
+    else:
+        trajs = [_mission_job(j) for j in jobs]
+    lens = np.array([t.shape[0] for t in trajs], dtype=np.int32)
+    out = np.zeros((count, int(lens.max()), NX))
+    for i, t in enumerate(trajs):
+        out[i, :t.shape[0]] = t
+        out[i, t.shape[0]:] = t[-1]
+    return out, lens
 
 
 def swarm_trajectories(seed: int, first_index: int, count: int, kind: str = "spline", **kw):

@@ -17,7 +17,7 @@ N, nb = 20, 10
 for c in which:
     b = int(d["b"][c])
     import bench
-    traj, lens = swarm_trajectories(2026, b, 1, kind=bench.TRAJECTORY_KIND, v_max=12.0, a_max=12.0)
+    traj, lens = bench.workload(2026, b, 1, 1000)
     e = Engine(EngineConfig(batch=1, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb)), lib_path=lib)
     e.set_trajectories(traj, lens)
     e.set_state(X=d["X"][c][None], U=d["U"][c][None], mu=d["mu"][c][None], C=d["C"][c][None], x_pred_prev=d["xpp"][c][None],
