@@ -1252,10 +1252,15 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const T
       const TQ dl = tdiv(rcl - ll * d, sl), du = tdiv(rcu + lu * d, su);
       S[L.z + i] += ap * d; S[L.sl + i] = sl + ap * d; S[L.su + i] = su - ap * d;
       S[L.ll + i] = ll + ad * dl; S[L.lu + i] = lu + ad * du;
+      // fp64: the gradient follows the step without a sweep.  The corrector solved (H + Sigma) dz = -rho with
+      // Sigma = ll/sl + lu/su of this iteration, so H dz = -rho - Sigma dz elementwise (the solve leaves a residual at the
+      // rounding level of double, far below the hand-over tolerance; the active-set iterations that follow recompute
+      // everything).  fp32 keeps the adjoint sweep: there the residual of the solve would pile up in the gradient.
+      if (sizeof(TQ) == 8) S[L.grad + GI(i)] += ap * (-S[L.rho + i] - (tdiv(ll, sl) + tdiv(lu, su)) * d);
     }
     for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
     __syncthreads();
-    PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
+    if (sizeof(TQ) == 4) { PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ); }
   }
   return status;
 }
