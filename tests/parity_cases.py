@@ -62,7 +62,7 @@ def case_teacher_forced_log(make_engine, name, K, precision=0, check_rgp=True):
         else:
             assert err < tol_k, (k, err)
         assert rel_err(xp, xpo, 1.0) < tol_k          # prediction and cost follow the control: same bound as that step's control
-        assert abs(e.get_cost()[0] - o.get_cost()[0]) <= 10 * tol_k * max(1.0, o.get_cost()[0])
+        assert abs(e.get_cost()[0] - o.get_cost()[0]) <= (10 if precision == 1 else 1) * tol_k * max(1.0, o.get_cost()[0])
         if cfg.nb and check_rgp:
             mu, C = e.get_rgp(); muo, Co = o.get_rgp()
             assert rel_err(mu, muo, 1.0) < (1e-10 if precision == 0 else 1e-4)
