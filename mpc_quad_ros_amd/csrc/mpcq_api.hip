@@ -14,6 +14,7 @@
 
 #include "../../include/mpcq.h"
 #include "mpcq_kernels.hpp"
+#include "mpcq_dense.hpp"
 
 namespace mpcq {   // mpcq_spec.hip, one translation unit per specialised shape
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
@@ -183,6 +184,9 @@ struct EngineT : mpcq_engine {
   double* h_pin = nullptr;   // pinned staging of the host-buffer step: [x_meas B*13 | w B*4 | x_pred B*13]
   double *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr, *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
   int* d_tlen = nullptr;
+  bool defer = false;        // two-phase lockstep period: interior-point solves in the dense kernel (mpcq_dense.hpp)
+  int parity = 0;            // which of the two deferral counters the next period uses
+  size_t dense_lds = 0;
   double* d_cmd = nullptr;   // [B*8] rotor thrusts, collective thrust, body rates (mpcq_get_command); also the chunk read-back
   size_t cmd_elems = 0;
   std::vector<T> hbuf;
@@ -190,7 +194,7 @@ struct EngineT : mpcq_engine {
 
   ~EngineT() override {
     DeviceGuard guard(cfg.device);
-    void* ptrs[] = {st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
+    void* ptrs[] = {st.defer_rec, st.defer_list, st.defer_cnt, st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
                     st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -349,6 +353,20 @@ struct EngineT : mpcq_engine {
       if (auto k = spec_step(N, nb, gab, false, (T*)nullptr)) kstep = k;
       if (auto k = spec_step(N, nb, gab, true, (T*)nullptr)) krun = k;
     }
+    // Two-phase period (fp64 engines with the stage records in global memory, horizons whose dense Hessian fits LDS): the
+    // interior-point solves of a period run in the dense kernel instead of inside the launch of the whole batch.
+    // OFF unless MPCQ_DEFER=1: measured on the bench workload the dense kernel takes 1.24 ms per period (one wave per CU,
+    // bound by LDS round trips in its triangular solves and tile loops) against ~0.5 ms for the same solves inside the
+    // step kernel; results are identical (tests/test_engine_edges.py::_two_phase_period).  DESIGN.md section 9.
+    defer = false;
+    if (const char* t = getenv("MPCQ_DEFER")) defer = atoi(t) != 0 && sizeof(T) == 8 && gab && N <= 20;
+    if (defer) {
+      dense_lds = mpcq::dense_lds_bytes(N);
+      if ((rc = dalloc(st.defer_rec, Bz * mpcq::defer_stride(N)))) return rc;
+      if ((rc = dalloc(st.defer_list, 2 * Bz))) return rc;
+      if ((rc = dalloc(st.defer_cnt, 2))) return rc;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::dense_ipm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_lds));
+    }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::regress_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -403,9 +421,21 @@ struct EngineT : mpcq_engine {
   int set_params(const double* mu) override { return nb ? h2q(st.mu, mu, (size_t)B * 3 * nb) : 0; }
 
   int base_mode() const { return (cfg.flags & MPCQ_FLAG_STATIC_GP) ? mpcq::MODE_STATIC_GP : 0; }
+  // One lockstep control period on the stream: the step kernel over the batch and, in the two-phase form, the dense
+  // interior-point kernel and the finishing launch over the quadrotors that deferred their solve (both return at once
+  // when the list of the period is empty).
+  void launch_period(const mpcq::DevState<T>& s, int mode) {
+    if (!defer) { hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode); return; }
+    const int pm = parity ? mpcq::MODE_PARITY : 0;
+    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode | mpcq::MODE_DEFER | pm);
+    const int nd = B < 256 ? B : 256;
+    hipLaunchKernelGGL(mpcq::dense_ipm_kernel<T>, dim3(nd), dim3(64), dense_lds, stream, m, s, parity);
+    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, (mode & ~mpcq::MODE_PLANT_FIRST) | mpcq::MODE_FINISH | pm);
+    parity ^= 1;
+  }
   int launch_step(int mode) {
     HIP_TRY(hipEventRecord(ev0, stream));
-    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, st, mode);
+    launch_period(st, mode);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
@@ -489,7 +519,7 @@ struct EngineT : mpcq_engine {
     s2.x_meas = d_x;
     if (d_w) s2.w = d_w;
     HIP_TRY(hipEventRecord(ev0, stream));
-    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode());
+    launch_period(s2, mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
@@ -516,7 +546,7 @@ struct EngineT : mpcq_engine {
       const bool timed_launch = k % stride == 0;
       const int mode = mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode() | ((!split && k > 0) ? mpcq::MODE_PLANT_FIRST : 0);
       if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride)], stream));
-      hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s2, mode);
+      launch_period(s2, mode);
       if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride) + 1], stream));
       if (split || k == K - 1)
         hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, sim_dt, B);

@@ -85,7 +85,13 @@ constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded 
 constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
 constexpr int SUBS = 4 * SUBW + 1;  // per-stage stride of the records (odd: lanes of different stages hit different banks)
 
-enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4, MODE_PLANT_FIRST = 8, MODE_STATIC_GP = 16 };
+enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4, MODE_PLANT_FIRST = 8, MODE_STATIC_GP = 16, MODE_DEFER = 32, MODE_FINISH = 64, MODE_PARITY = 128 };
+// MODE_DEFER / MODE_FINISH / MODE_PARITY: two-phase lockstep period (mpcq_dense.hpp).  A quadrotor whose warm active-set attempt is given
+// up does not run its interior-point solve inside the launch of the whole batch (it would hold the launch for ~0.5 ms while every other
+// workgroup has finished): it leaves its QP data in DevState::defer_rec and its index in the list of the period (MODE_DEFER); the dense
+// interior-point kernel solves the listed QPs, and a MODE_FINISH launch of this kernel over the list takes the step from there
+// (active-set iterations from the interior point's working set, full step, post phase).  MODE_PARITY selects which of the two list
+// counters the period uses.
 // MODE_STATIC_GP: the GP of the model is fixed (mpcq_config.flags & MPCQ_FLAG_STATIC_GP): the post phase skips the RGP update.
 // MODE_RUN: free-running closed loop, DevState::run_* periods per launch.  MODE_PLANT_FIRST: the launch starts by
 // advancing the plant state run_x with the previous launch's control (lockstep closed loop without a plant kernel
@@ -160,6 +166,9 @@ struct DevState {
   int* qp_iter;
   int* finished;    // [B] trajectory finished (src/mpc_controller_node.py:374), sticky until new trajectories / reset
   TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
+  double* defer_rec;   // [B][defer_stride(N)] QP data in / interior point out of the deferred solves (two-phase period)
+  int* defer_list;     // [2][B] indices of the quadrotors deferred in this period, per counter parity
+  int* defer_cnt;      // [2]
   double* run_x;    // [B][13] plant states of the free-running closed loop (MODE_RUN; aliases x_meas)
   int run_steps, run_nsub;   // control periods per launch, plant substeps per period
   double run_dt;    // plant substep
@@ -237,6 +246,8 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   L.qtotal = o;
   return L;
 }
+// deferred-solve record (doubles): r0 lb ub [nv each] | dx0 [16] | z sl su ll lu [nv each] | gm, iterations, status, pad [16]
+__host__ __device__ inline int defer_stride(int N) { return 8 * N * NU + 32; }
 template <typename TQ> __host__ __device__ inline size_t lds_bytes(const Lds& L) { return (size_t)L.dbytes + (size_t)L.qtotal * sizeof(TQ); }
 
 // ------------------------------------------------------------------ small helpers
@@ -1649,7 +1660,8 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const int prev_iter PF_ARG) {
+MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const int prev_iter, const int phase_in, double* rec PF_ARG) {
+  const int phase = C::RUN ? 0 : phase_in;   // the free-running instances have no two-phase period
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0;
   TQ gm = 1;
@@ -1658,8 +1670,10 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
   // many inputs every period) fails the warm attempt period after period: after a fallback the next attempt is short
   // (warm_retry passes), so that such a quadrotor costs its launch one interior-point solve, not that plus a long
   // active-set attempt; the first period in which the short attempt succeeds restores the full budget.
+  // phase: 0 = everything inside this launch; MODE_DEFER = give the interior-point solve away (returns -1);
+  //        MODE_FINISH = the interior point comes from the dense kernel (rec), continue behind it
   const int warm_cap = prev_iter >= 1000 ? m.warm_retry : m.warm_max;
-  if (prev_iter > 0 && warm_cap > 0) {
+  if (phase != MODE_FINISH && prev_iter > 0 && warm_cap > 0) {
     if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap PF_PASS)
                         : polish_incremental<C>(m, S, A, L, gm, wpasses, true, warm_cap PF_PASS)) {   // sets z = 0 and its own gradient scale
       *status = 0;
@@ -1667,6 +1681,29 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
     }
     wpasses += 1000;
   }
+  int st = 0;
+  if (!C::RUN && phase == MODE_DEFER) {
+    for (int i = tid; i < nv; i += 64) { rec[i] = (double)S[L.r0 + i]; rec[nv + i] = (double)S[L.lb + i]; rec[2 * nv + i] = (double)S[L.ub + i]; }
+    if (tid < VS) rec[3 * nv + tid] = (double)S[L.dx + tid];
+    if (tid == 0) rec[3 * nv + 16 + 5 * nv + 3] = (double)wpasses;
+    return -1;
+  }
+  bool from_dense = false;
+  if (!C::RUN && phase == MODE_FINISH) {
+    const double* o = rec + 3 * nv + 16;
+    from_dense = o[5 * nv + 2] == 0.0;      // the dense interior point converged
+    wpasses = (int)o[5 * nv + 3];   // 1000 + passes of the warm attempt the main launch gave up (0 after a cold start)
+    if (from_dense) {
+      for (int i = tid; i < nv; i += 64) {
+        S[L.z + i] = (TQ)o[i]; S[L.sl + i] = (TQ)o[nv + i]; S[L.su + i] = (TQ)o[2 * nv + i];
+        S[L.ll + i] = (TQ)o[3 * nv + i]; S[L.lu + i] = (TQ)o[4 * nv + i];
+      }
+      gm = (TQ)o[5 * nv];
+      it = (int)o[5 * nv + 1];
+      __syncthreads();
+    }
+  }
+  if (!from_dense) {
   // interior start
   for (int i = tid; i < nv; i += 64) {
     const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
@@ -1681,7 +1718,8 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
   gm = wave_max(gm);
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = TQ(0.1) * gm / S[L.sl + i]; S[L.lu + i] = TQ(0.1) * gm / S[L.su + i]; }
   __syncthreads();
-  int st = ipm_run<C>(m, S, A, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+  st = ipm_run<C>(m, S, A, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+  }
   bool need_roll = true;
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
@@ -1772,8 +1810,18 @@ __device__ inline int chunk_have(int len, int idx, int N, int skip) {
 
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
-  const int b = blockIdx.x, tid = lane_id();
+  const int tid = lane_id();
   const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
+  // two-phase period (not in the free-running instances): which quadrotor this workgroup works on
+  const int phase = C::RUN ? 0 : (mode & (MODE_DEFER | MODE_FINISH));
+  const int par = (mode & MODE_PARITY) ? 1 : 0;
+  int b = blockIdx.x;
+  if (!C::RUN && phase == MODE_FINISH) {
+    if ((int)blockIdx.x >= st.defer_cnt[par]) return;
+    b = st.defer_list[par * m.B + blockIdx.x];
+  } else if (!C::RUN && phase == MODE_DEFER && blockIdx.x == 0 && tid == 0) {
+    st.defer_cnt[par ^ 1] = 0;   // the other period's counter: nobody touches it during this one
+  }
   const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
   double* D = reinterpret_cast<double*>(smem_raw);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
@@ -1891,13 +1939,15 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   }
   __syncthreads();
   PF_STOP(PF_LOAD);
-  // ---- 1. shooting
-  shoot_states<C>(m, D, S, A, L, gp);
-  __syncthreads();
-  PF_STOP(PF_SHOOT_X);
-  shoot_sens<C>(m, S, A, L);
-  __syncthreads();
-  PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
+  // ---- 1. shooting (a MODE_FINISH launch finds the stage records of this period in the global record)
+  if (phase != MODE_FINISH) {
+    shoot_states<C>(m, D, S, A, L, gp);
+    __syncthreads();
+    PF_STOP(PF_SHOOT_X);
+    shoot_sens<C>(m, S, A, L);
+    __syncthreads();
+    PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
+  }
   if (tid < VS) { S[L.dx + tid] = 0; A[L.AB + N * ABS + tid] = 0; S[L.zb + tid] = 0; }
   for (int it = tid; it < N * VS; it += 64) S[L.vin + it] = 0;
   __syncthreads();
@@ -1905,7 +1955,12 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b] PF_PASS);
+  double* rec = (!C::RUN && phase) ? st.defer_rec + (size_t)b * defer_stride(N) : nullptr;
+  const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b], phase, rec PF_PASS);
+  if (!C::RUN && iters < 0) {   // deferred: nothing of this period has been written yet; the finish launch does the rest
+    if (tid == 0) st.defer_list[par * m.B + atomicAdd(&st.defer_cnt[par], 1)] = b;
+    return;
+  }
   PF_START();
   // ---- 3. full step (iterate accumulated in double).  A step that is not finite (a QP that broke down: only seen
   //      with the fp32 QP on infeasible references) is not taken: the iterate and the control of the previous period

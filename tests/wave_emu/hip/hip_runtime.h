@@ -57,6 +57,7 @@ template <typename T> inline T __shfl_xor(T v, int mask) {
   std::memcpy(&r, &raw, sizeof(T));
   return r;
 }
+inline int atomicAdd(int* p, int v) { const int old = *p; *p = old + v; return old; }   // lanes run one after another
 inline float __expf(float x) { return std::exp(x); }
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 inline float __fdividef(float a, float b) { return a / b; }
