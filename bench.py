@@ -59,11 +59,13 @@ def workload(seed, first_index, B, periods):
     return swarm_missions(seed, first_index, B, periods + 150, v_max=12.0, a_max=12.0)
 
 
-def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None, periods=1000):
+def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None, periods=1000, refs=None):
+    """refs: (traj, lens) generated earlier -- the generator forks worker processes, which is done BEFORE this process
+    touches the GPU."""
+    traj, lens = refs if refs is not None else workload(seed, first_index, B, periods)
     cfg = EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb),
                        theta=[1.0, 0.1, 0.1], dt_pred=0.01, device=device, precision=precision)
     e = Engine(cfg, lib_path=lib_path)
-    traj, lens = workload(seed, first_index, B, periods)
     e.set_trajectories(traj, lens)
     e.sim_reset(np.tile(X0, (B, 1)))
     return e, cfg
@@ -87,7 +89,7 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(N, nb, seed, budget_s=18.0):
+def cpu_baseline(N, nb, seed, budget_s=18.0, refs=None):
     """The fp64 CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload (same trajectories, same
     pre-rolled regime is not reproduced: the sample starts at hover and runs closed loop), swept over OpenMP team
     sizes {1, physical cores, all hardware threads}; the best is `value`, the single-thread figure rides along.
@@ -117,7 +119,10 @@ def cpu_baseline(N, nb, seed, budget_s=18.0):
                            theta=[1.0, 0.1, 0.1], dt_pred=0.01)
         o = OracleEngine(cfg, native=native)
         o.set_threads(threads)
-        traj, lens = workload(seed, 0, B, 500)
+        if refs is not None and refs[0].shape[0] >= B:      # the first B quadrotors of the GPU run's own references
+            traj, lens = refs[0][:B], refs[1][:B]
+        else:
+            traj, lens = workload(seed, 0, B, 500)
         o.set_trajectories(traj, lens)
         x = np.tile(X0, (B, 1))
         for _ in range(2):
@@ -200,7 +205,8 @@ def main():
     prec = PRECISION_F64 if args.precision == "f64" else PRECISION_F32
     itemsize = 8 if prec == PRECISION_F64 else 4
     periods = args.preroll + args.warmup + args.steps
-    e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods)
+    refs = workload(args.seed, rank * B, B, periods)      # host-side generation (worker processes) before the GPU is touched
+    e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods, refs=refs)
     stats_reduce = "single"
     rccl_hung = False
     if world > 1:
@@ -327,7 +333,7 @@ def main():
             # measurements gets per tick, this one is the capacity of the device as a closed-loop swarm simulator.
             x_lock, w_lock = e.sim_get_state()
             e.close()
-            e3, _ = make_engine(B, N, nb, prec, local_rank, 0, args.seed, periods=periods)
+            e3, _ = make_engine(B, N, nb, prec, local_rank, 0, args.seed, periods=periods, refs=refs)
             e3.sim_run(args.preroll + args.warmup, n_sub, 5e-3)
             e3.lib.mpcq_synchronize(e3.h)
             ta = time.perf_counter()
@@ -344,7 +350,7 @@ def main():
                                            "slowest instance of the batch"}
             e3.close()
             alt = "f32" if args.precision == "f64" else "f64"
-            e2, _ = make_engine(B, N, nb, PRECISION_F32 if alt == "f32" else PRECISION_F64, local_rank, 0, args.seed, periods=periods)
+            e2, _ = make_engine(B, N, nb, PRECISION_F32 if alt == "f32" else PRECISION_F64, local_rank, 0, args.seed, periods=periods, refs=refs)
             e2.sim_steps(args.preroll + args.warmup, n_sub, 5e-3)
             e2.lib.mpcq_synchronize(e2.h)
             ta = time.perf_counter()
@@ -361,7 +367,7 @@ def main():
                                             "Both place 4 quadrotors per CU"}
             e2.close()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, nb, args.seed)
+            out["cpu_baseline"] = cpu_baseline(N, nb, args.seed, refs=refs)
         print(json.dumps(out))
     rccl_ok = world == 1 or stats_reduce == "rccl"
     if dist is not None:
