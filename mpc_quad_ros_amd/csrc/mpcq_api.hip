@@ -254,10 +254,18 @@ struct EngineT : mpcq_engine {
     if (const char* t = getenv("MPCQ_IPM_TOL")) m.ipm_tol = (T)atof(t);
     if (const char* t = getenv("MPCQ_POLISH_MAX")) m.polish_max = atoi(t);
     // passes of the warm active-set attempt before falling back to the IPM (fp64: one factorisation each, an interior-point
-    // solve costs about 15 of them; measured on the min-snap bench workload, lockstep: 24 -> 1.14 M steps/s, 10 -> 1.21 M, 6 -> 1.31 M)
-    m.warm_max = f32 ? 12 : 8;
+    // solve costs about 15 of them; measured on the min-snap bench workload, lockstep,
+    // with the interior point started at 0.1: 24 -> 1.14 M steps/s, 10 -> 1.21 M, 6 -> 1.31 M; started at 1e-4: 10/3 -> 1.56 M, 8/2 -> 1.67 M, 6/1 -> 1.80 M, 4/1 -> 1.82 M)
+    m.warm_max = f32 ? 12 : 6;
     if (const char* t = getenv("MPCQ_WARM_MAX")) m.warm_max = atoi(t);
-    m.warm_retry = 2;
+    m.ipm_margin = (T)0.1;
+    if (const char* t = getenv("MPCQ_IPM_MARGIN")) m.ipm_margin = (T)atof(t);
+    // complementarity of the interior start in units of the gradient scale.  The start is the previous solution pushed inside the
+    // box, i.e. close to the new optimum: a small value makes it a warm start (measured, bench workload, fp64 lockstep:
+    // 0.1 -> 1.36 M steps/s, 1e-2 -> 1.44, 1e-3 -> 1.54, 1e-4 -> 1.68, 1e-5 -> 1.61, 1e-6 -> 1.44)
+    m.ipm_mu0 = (T)1e-4;   // fp32 lockstep: 0.1 -> 1.63 M, 1e-4 -> 2.01 M
+    if (const char* t = getenv("MPCQ_IPM_MU0")) m.ipm_mu0 = (T)atof(t);
+    m.warm_retry = 1;
     if (const char* t = getenv("MPCQ_WARM_RETRY")) m.warm_retry = atoi(t);
     m.pdas_max = 0;   // passes in which pins and releases may happen together (fp64 active-set method; measured on the bench workload: such passes are rare, 0.2 % of the quadrotor-steps, and the multiplier evaluations they need cost 4 % of the launch time)
     if (const char* t = getenv("MPCQ_PDAS")) m.pdas_max = atoi(t);
@@ -429,7 +437,7 @@ struct EngineT : mpcq_engine {
     const int pm = parity ? mpcq::MODE_PARITY : 0;
     hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode | mpcq::MODE_DEFER | pm);
     const int nd = B < 256 ? B : 256;
-    hipLaunchKernelGGL(mpcq::dense_ipm_kernel<T>, dim3(nd), dim3(64), dense_lds, stream, m, s, parity);
+    hipLaunchKernelGGL(mpcq::dense_ipm_kernel<T>, dim3(nd), dim3(mpcq::DT), dense_lds, stream, m, s, parity);
     hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, (mode & ~mpcq::MODE_PLANT_FIRST) | mpcq::MODE_FINISH | pm);
     parity ^= 1;
   }

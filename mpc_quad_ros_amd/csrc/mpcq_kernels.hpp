@@ -138,6 +138,8 @@ struct DevModel {
   double finish_r;   // EPSILON_TRAJECTORY_FINISHED (src/mpc_controller_node.py:118)
   TQ qp_tol;    // final KKT tolerance (IPM-only fallback)
   TQ ipm_tol;   // IPM -> active-set polish hand-over tolerance
+  TQ ipm_margin;   // interior start: distance from the bounds in units of their width
+  TQ ipm_mu0;   // initial complementarity of the interior start, in units of the gradient scale
   TQ eps;       // unit roundoff scale of TQ used for KKT sign / bound tests
   TQ L2inv[3], sf2[3], sn2[3];
   const TQ* basis;  // [3*nb]
@@ -1707,7 +1709,7 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
   // interior start
   for (int i = tid; i < nv; i += 64) {
     const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
-    const TQ z0 = tmin(tmax(TQ(0), lb + TQ(0.1) * w), ub - TQ(0.1) * w);
+    const TQ z0 = tmin(tmax(TQ(0), lb + m.ipm_margin * w), ub - m.ipm_margin * w);
     S[L.z + i] = z0; S[L.sl + i] = z0 - lb; S[L.su + i] = ub - z0;
   }
   __syncthreads();
@@ -1716,7 +1718,7 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
   gm = 1;
   for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
   gm = wave_max(gm);
-  for (int i = tid; i < nv; i += 64) { S[L.ll + i] = TQ(0.1) * gm / S[L.sl + i]; S[L.lu + i] = TQ(0.1) * gm / S[L.su + i]; }
+  for (int i = tid; i < nv; i += 64) { S[L.ll + i] = m.ipm_mu0 * gm / S[L.sl + i]; S[L.lu + i] = m.ipm_mu0 * gm / S[L.su + i]; }
   __syncthreads();
   st = ipm_run<C>(m, S, A, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
   }
