@@ -25,6 +25,9 @@ int mpcq_minsnap_estimate_times(const double* wp, int32_t n, double v_max, doubl
 int mpcq_minsnap_solve(const double* wp, int32_t n, const double* T, double* pieces);
 /* estimate + solve + uniform time scaling until the sampled peak speed / acceleration meet v_max / a_max */
 int mpcq_minsnap_generate(const double* wp, int32_t n, double v_max, double a_max, double* pieces);
+/* pieces -> sampled 13-state reference x [cap,13] every dt (save_evals_csv + load_trajectory, TrajectoryGenerator.py:208-244:
+ * 6-decimal rounding, q = [1,0,0,0], rates 0); returns the number of rows or -1 (cap too small / bad arguments) */
+int mpcq_minsnap_sample(const double* pieces, int32_t nseg, double dt, double* x, int32_t cap);
 /* polynomial_representation.csv in the reference's format ("%.6f", header line) */
 int mpcq_minsnap_write_csv(const char* path, const double* pieces, int32_t nseg);
 

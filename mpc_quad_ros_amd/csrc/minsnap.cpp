@@ -218,6 +218,39 @@ int mpcq_minsnap_generate(const double* wp, int32_t n, double v_max, double a_ma
   return violation(hi) <= 1.0 ? 0 : -3;
 }
 
+// Sampling of the pieces into the 13-state reference, the chain save_evals_csv -> load_trajectory of the reference
+// (src/trajectory_generation/TrajectoryGenerator.py:208-244): t_k = k dt for t_k < total duration, piece lookup by the running
+// sum of the durations (uav_trajectory.py:146-150), Horner evaluation with the highest power first (uav_trajectory.py:22-28),
+// positions and velocities rounded to the CSV's 6 decimals, q = [1,0,0,0], body rates 0.  Same operations in the same order as
+// mpc_quad_ros_amd.trajectories.sample_polynomial_trajectory (bit-identical; built with -ffp-contract=off).
+// x [cap, 13]; returns the number of rows, or -1 if cap is too small / bad arguments.
+int mpcq_minsnap_sample(const double* pieces, int32_t nseg, double dt, double* x, int32_t cap) {
+  if (!pieces || !x || nseg < 1 || !(dt > 0)) return -1;
+  double total = 0;
+  std::vector<double> ends(nseg);
+  for (int s = 0; s < nseg; ++s) { total = total + pieces[(size_t)s * 33]; ends[s] = total; }
+  const int T = (int)std::ceil(total / dt);      // len(np.arange(0, total, dt))
+  if (T > cap) return -1;
+  int seg = 0;
+  for (int k = 0; k < T; ++k) {
+    const double t = k * dt;
+    while (seg < nseg - 1 && !(t < ends[seg])) ++seg;      // first piece whose end lies beyond t
+    const double tl = t - (seg > 0 ? ends[seg - 1] : 0.0);
+    double* row = x + (size_t)k * 13;
+    for (int i = 0; i < 13; ++i) row[i] = 0.0;
+    row[3] = 1.0;
+    for (int a = 0; a < 3; ++a) {
+      const double* c = pieces + (size_t)seg * 33 + 1 + 8 * a;
+      double p = 0.0, v = 0.0;
+      for (int i = 0; i < 8; ++i) p = p * tl + c[7 - i];
+      for (int i = 0; i < 7; ++i) v = v * tl + (7 - i) * c[7 - i];
+      row[a] = std::nearbyint(p * 1e6) / 1e6;            // np.round(., 6): rint(x * 1e6) / 1e6, ties to even
+      row[7 + a] = std::nearbyint(v * 1e6) / 1e6;
+    }
+  }
+  return T;
+}
+
 // The reference's polynomial CSV (uav_trajectory.Trajectory.savecsv, src/trajectory_generation/uav_trajectory.py:116-129):
 // header line, then per segment 33 numbers with "%.6f".
 int mpcq_minsnap_write_csv(const char* path, const double* pieces, int32_t nseg) {

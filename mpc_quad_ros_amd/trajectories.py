@@ -111,6 +111,7 @@ def _traj_lib():
         lib.mpcq_minsnap_solve.argtypes = [dp, ctypes.c_int32, dp, dp]
         lib.mpcq_minsnap_generate.argtypes = [dp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, dp]
         lib.mpcq_minsnap_write_csv.argtypes = [ctypes.c_char_p, dp, ctypes.c_int32]
+        lib.mpcq_minsnap_sample.argtypes = [dp, ctypes.c_int32, ctypes.c_double, dp, ctypes.c_int32]
         _TRAJ_LIB = lib
     return _TRAJ_LIB
 
@@ -155,6 +156,18 @@ def write_polynomial_csv(path, pieces):
         raise OSError(f"cannot write {path}")
 
 
+def sample_polynomial_trajectory_native(pieces, dt: float = 0.01):
+    """sample_polynomial_trajectory in C++ (mpcq_minsnap_sample: same operations in the same order, bit-identical; releases the
+    GIL, so many trajectories can be sampled from Python threads)."""
+    pieces = np.ascontiguousarray(np.atleast_2d(np.asarray(pieces, dtype=np.float64))[:, :33])
+    cap = int(np.ceil(float(np.sum(pieces[:, 0])) / dt)) + 2
+    x = np.zeros((cap, NX))
+    n = _traj_lib().mpcq_minsnap_sample(_dptr(pieces), len(pieces), float(dt), _dptr(x), cap)
+    if n < 0:
+        raise ValueError("mpcq_minsnap_sample failed")
+    return x[:n], np.round(np.arange(n) * dt, 6)
+
+
 def minsnap_trajectory(seed: int, index: int, v_max: float = 12.0, a_max: float = 12.0, dt: float = 0.01, **kw):
     """The node's 'random' request through the min-snap generator: x_ref [T, 13] sampled every dt."""
     pieces = minsnap_pieces(random_waypoints(seed, index, **kw), v_max, a_max)
@@ -169,7 +182,7 @@ def minsnap_mission(seed: int, index: int, min_samples: int, v_max: float = 12.0
     rows, start, leg, n = [], np.asarray(kw.pop("start", HOVER), dtype=float), 0, 0
     while n < min_samples:
         wp = random_waypoints([int(seed), 7919 * (leg + 1)], index, start=start, **kw)
-        x = sample_polynomial_trajectory_fast(minsnap_pieces(wp, v_max, a_max), dt)[0]
+        x = sample_polynomial_trajectory_native(minsnap_pieces(wp, v_max, a_max), dt)[0]
         rows.append(x)
         n += len(x)
         start, leg = wp[-1], leg + 1
@@ -181,12 +194,13 @@ def _mission_job(args):
 
 
 def swarm_missions(seed: int, first_index: int, count: int, min_samples: int, **kw):
-    """Padded batch of missions (see minsnap_mission): (traj [count, Tmax, 13], lengths [count]); generated on all host cores."""
+    """Padded batch of missions (see minsnap_mission): (traj [count, Tmax, 13], lengths [count]); generated by a pool of host threads."""
     jobs = [((seed, first_index + i, min_samples), kw) for i in range(count)]
-    if count >= 256:
-        import multiprocessing as mp
-        with mp.get_context("fork").Pool(min(mp.cpu_count(), 32)) as pool:
-            trajs = pool.map(_mission_job, jobs, chunksize=max(1, count // 256))
+    if count >= 64:      # threads, not processes: the solver and the sampler are C++ calls that release the GIL
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as pool:
+            trajs = list(pool.map(_mission_job, jobs))
     else:
         trajs = [_mission_job(j) for j in jobs]
     lens = np.array([t.shape[0] for t in trajs], dtype=np.int32)

@@ -39,7 +39,7 @@ def test_header_and_library_agree():
     hdr = open(os.path.join(ROOT, "include", "mpcq_traj.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(mpcq_minsnap_[a-z0-9_]+)\s*\(", hdr)))
-    assert names == ["mpcq_minsnap_estimate_times", "mpcq_minsnap_generate", "mpcq_minsnap_solve", "mpcq_minsnap_write_csv"]
+    assert names == ["mpcq_minsnap_estimate_times", "mpcq_minsnap_generate", "mpcq_minsnap_sample", "mpcq_minsnap_solve", "mpcq_minsnap_write_csv"]
     lib = ctypes.CDLL(os.path.join(ROOT, "mpc_quad_ros_amd", "libmpcq_traj.so"))
     for n in names:
         assert hasattr(lib, n), n
@@ -121,17 +121,19 @@ def test_csv_roundtrip_in_reference_format(tmp_path):
     back = np.loadtxt(path, delimiter=",", skiprows=1, usecols=range(33), ndmin=2)
     assert back.shape == P.shape and np.abs(back - P).max() <= 0.5e-6
     assert open(path).readline().startswith("# duration,x^0,x^1")
-    xa, _ = tr.sample_polynomial_trajectory_fast(back, 0.01)
-    xb, _ = tr.sample_polynomial_trajectory(back, 0.01)
-    assert np.array_equal(xa, xb)                                      # the vectorised sampler is the reference-pinned one
+    xa, ta = tr.sample_polynomial_trajectory_fast(back, 0.01)
+    xb, tb = tr.sample_polynomial_trajectory(back, 0.01)
+    xc, tc = tr.sample_polynomial_trajectory_native(back, 0.01)
+    assert np.array_equal(xa, xb) and np.array_equal(xa, xc) and np.array_equal(ta, tc)     # the vectorised and the C++ sampler are the reference-pinned one
 
 
 def test_fast_sampler_matches_reference_generated_vectors():
     g = np.load(os.path.join(ROOT, "tests", "golden", "poly_vectors.npz"))
     for c in range(int(g["ncases"])):
-        x, t = tr.sample_polynomial_trajectory_fast(g[f"p{c}_pieces"], float(g[f"p{c}_dt"]))
-        assert x.shape == g[f"p{c}_x"].shape
-        assert np.abs(x - g[f"p{c}_x"]).max() <= 1.5e-6 and np.abs(t - g[f"p{c}_t"]).max() < 1e-9
+        for sampler in (tr.sample_polynomial_trajectory_fast, tr.sample_polynomial_trajectory_native):
+            x, t = sampler(g[f"p{c}_pieces"], float(g[f"p{c}_dt"]))
+            assert x.shape == g[f"p{c}_x"].shape
+            assert np.abs(x - g[f"p{c}_x"]).max() <= 1.5e-6 and np.abs(t - g[f"p{c}_t"]).max() < 1e-9
 
 
 def test_swarm_is_partition_invariant_and_tracks_estimate():
