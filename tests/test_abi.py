@@ -55,3 +55,12 @@ def test_no_gpu_fails_loudly():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_lib.MpcqError, match="no CPU implementation"):
         _lib.load(str(tmp_path / "libmpcq.so"))
+
+
+def test_toolchain_is_the_validated_one():
+    """The kernels are validated with ROCm 7.2's hipcc (every instance at -O3; DESIGN.md section 3.5 records two
+    code-generation observations with this compiler).  A different toolchain has to re-run the GPU suite, in particular
+    test_kernel_variants_agree and tools/o3_discrepancy_probe.py, before its build is trusted."""
+    import subprocess
+    out = subprocess.check_output(["/opt/rocm/bin/hipcc", "--version"]).decode()
+    assert "HIP version: 7.2" in out, out.splitlines()[0]

@@ -220,6 +220,32 @@ def test_whole_trajectories_full_batch(precision):
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
+def test_missions_soak_full_batch():
+    """The bench workload (continuous operation on min-snap flights at v_max = a_max = 12: some quadrotors saturate for whole
+    stretches and need the interior point period after period) at full size for 1 500 control periods: every solve succeeds,
+    the fallback is exercised thousands of times, tracking stays bounded, and the free-running launch reproduces the per-period
+    launches bit for bit."""
+    import bench
+    B, K = 1024, 1500
+    refs = bench.workload(2026, 0, B, K)
+    out = []
+    for mode in ("sim_steps", "sim_run"):
+        e, _ = bench.make_engine(B, 20, 10, 0, 0, 0, 2026, periods=K, refs=refs)
+        fallbacks = 0
+        for chunk in range(K // 100):
+            getattr(e, mode)(100, 2, 5e-3)
+            assert (e.get_status() == 0).all(), (mode, chunk)
+            fallbacks += int((e.get_qp_iter() >= 1000).sum())
+        st = e.get_tracking_stats()
+        assert st[2] == K * B and st[4] == 0
+        assert np.sqrt(st[0] / (3 * st[2])) < 0.1 and np.sqrt(st[3]) < 3.0     # rms / worst position error [m]
+        out.append((e.sim_get_state(), e.get_state()["U"], st, fallbacks))
+        e.close()
+    assert out[0][3] > 20                       # interior-point fallbacks seen at the sampled periods alone
+    assert np.array_equal(out[0][0][0], out[1][0][0]) and np.array_equal(out[0][0][1], out[1][0][1])
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
 def test_config2_full_size():
     """BASELINE configs[2] at full size (8 192 quadrotors, 20 RGP basis points per axis; any-shape kernel instance, eight
     rounds of workgroups): both launch modes agree bit for bit, every instance solves, controls respect the box."""
