@@ -302,6 +302,27 @@ __device__ inline int xrow2(int v) {
 }
 __device__ inline float xrow2(float v) { return __int_as_float(xrow2(__float_as_int(v))); }
 __device__ inline double xrow2(double v) { return __hiloint2double(xrow2(__double2hiint(v)), xrow2(__double2loint(v))); }
+// sum over the four 16-lane rows (lanes c, c+16, c+32, c+48), result on every lane: after v_permlane16_swap(v, v) the two
+// outputs hold rows (0,0,2,2) and (1,1,3,3), after v_permlane32_swap rows (0,1,0,1) and (2,3,2,3) -- their sum is the
+// butterfly step on every lane, no select (gfx950; no LDS, no SGPR round trip)
+__device__ inline float hsum(float v) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const unsigned b = (unsigned)__float_as_int(v);
+  const u2 r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  const float w = __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+  const unsigned b2 = (unsigned)__float_as_int(w);
+  const u2 q = __builtin_amdgcn_permlane32_swap(b2, b2, false, false);
+  return __int_as_float((int)q[0]) + __int_as_float((int)q[1]);
+}
+__device__ inline double hsum(double v) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const u2 rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double w = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+  const unsigned lo2 = (unsigned)__double2loint(w), hi2 = (unsigned)__double2hiint(w);
+  const u2 ql = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false), qh = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+  return __hiloint2double((int)qh[0], (int)ql[0]) + __hiloint2double((int)qh[1], (int)ql[1]);
+}
 // wave-wide reductions: butterfly inside each row of 16 with DPP, then the 4 row results through SGPRs
 template <typename T, typename OP> __device__ inline T wave_reduce(T v, OP op) {
   v = op(v, dpp<0xB1>(v));    // quad_perm [1,0,3,2]
@@ -879,8 +900,63 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
 // forward sweep: Dx_0 = 0; dz_i = K_i Dx_i + k_i ; Dx_{i+1} = A Dx_i + B dz_i   (out: S[dzo], S[L.Dx])
 // affine: the sweep of the affine recursion instead: starts from dx_0 in S[L.dx], adds the gaps (S[L.Dx]) and writes the
 // state trajectory to S[L.dx] (z_i = K_i dx_i + k_i to S[dzo])
+// A matrix-vector product uses one of the 16 columns of a tile, and v_mfma_f64_16x16x4 occupies the matrix pipe for 16 passes
+// whatever the columns hold: the sweeps do their two products per stage on the vector ALU instead, with the SAME operand
+// registers (lane (h,c) holds M[c][RI(s,h)], s = 0..3): four FMAs against the group-uniform vector slots x[RI(s,h)], then
+// the sum over the four lane rows (hsum).  The result arrives lane-indexed (lane (.,c) holds row c); the next product needs
+// it group-uniform again: the inputs go through four v_readlane, the state through the LDS vector that the sweep writes anyway.
 template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
+#ifndef MPCQ_MFMA_SWEEPS
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
+  const Sel<TQ> sel(h);
+  const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c), rk(L.zb, L.K, KS, NU, h, c);
+  constexpr int PD = Depth<GAB>::PD;
+  const int xo = affine ? L.dx : L.Dx;
+  const bool prow = c >= 10 && c < NX;   // position rows: identity block of [A|B]
+  TQ xv[4] = {0, 0, 0, 0}, xc = 0, qa[PD + 1][4], kc[4], kn[4], kv, kvn, gc = 0, gcn = 0;
+  if (affine) { vl_load(S + L.dx, h, xv); xc = S[L.dx + c]; gc = S[L.Dx + c]; }
+  else if (lane < VS) S[L.Dx + lane] = 0;
+#pragma unroll
+  for (int d = 0; d < PD; ++d) rm.load(A, d < N ? d : N - 1, qa[d]);
+  rk.load(S, 0, kc);
+  kv = S[L.vin + c];
+#pragma unroll MPCQ_UNROLL_SWEEP
+  for (int i = 0; i < N; ++i) {
+    const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1;
+    rm.load(A, ig, qa[PD]);
+    rk.load(S, ip, kn);
+    kvn = S[L.vin + ip * VS + c];
+    if (affine) gcn = S[L.Dx + ip * VS + c];
+    PF_FINE(11);
+    // dz = K Dx + k: lanes (., c < 4)
+    TQ t = (kc[0] * xv[0] + kc[1] * xv[1]) + (kc[2] * xv[2] + kc[3] * xv[3]);
+    // the state part of the second product does not wait for dz
+    TQ ta = (qa[0][0] * (sel.A[0] * xv[0]) + qa[0][1] * (sel.A[1] * xv[1])) + (qa[0][2] * (sel.A[2] * xv[2]) + qa[0][3] * (sel.A[3] * xv[3]));
+    const TQ u = hsum(t) + kv;
+    PF_FINE(12);
+    if (lane < NU) S[dzo + i * NU + lane] = u;
+    TQ d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = bc(u, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (h == in_h<TQ>(j)) ta += qa[0][in_s<TQ>(j)] * d[j];
+    PF_FINE(13);
+    TQ xn = hsum(ta) + (prow ? xc : TQ(0)) + (affine ? gc : TQ(0));
+    xn = c < NX ? xn : TQ(0);
+    PF_FINE(14);
+    xc = xn;
+    if (lane < VS) S[xo + (i + 1) * VS + lane] = xn;
+    __syncthreads();
+    vl_load(S + xo + (i + 1) * VS, h, xv);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kc[s] = kn[s];
+    kv = kvn; gc = gcn;
+    shift<TQ, PD>(qa);
+  }
+  __syncthreads();
+#else
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   const Sel<TQ> sel(h);
@@ -947,6 +1023,7 @@ MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& 
     if (vl) vl_store(S + xo + (i + 1) * VS, h, vA);
   }
   __syncthreads();
+#endif
 }
 
 // ------------------------------------------------------------------ QP: Riccati factorisation

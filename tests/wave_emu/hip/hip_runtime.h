@@ -139,6 +139,19 @@ inline emu_u2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, boo
   emu::sync();
   return r;
 }
+// v_permlane16_swap_b32 (gfx950): the odd 16-lane rows of `a` are exchanged with the even rows of `b`; returns {new a, new b}
+inline emu_u2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+  uint64_t* ea = emu::exchange();
+  uint64_t* eb = emu::exchange2();
+  const unsigned t = emu::cur->tid.x, w = t & ~63u, l = t & 63u;
+  ea[t] = a; eb[t] = b;
+  emu::sync();
+  emu_u2 r;
+  r[0] = (l & 16) ? (unsigned)eb[w + l - 16] : a;
+  r[1] = (l & 16) ? b : (unsigned)ea[w + l + 16];
+  emu::sync();
+  return r;
+}
 template <typename T> inline T __shfl(T v, int src) {
   static_assert(sizeof(T) <= 8, "shuffle payload");
   uint64_t* ex = emu::exchange();
