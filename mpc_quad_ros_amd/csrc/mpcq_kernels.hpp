@@ -772,9 +772,48 @@ __host__ __device__ inline int GI(int i) { return (i >> 2) * VS + 10 + (i & 3); 
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dxo, int zo, bool with_c) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
-  const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[zo + i];
   __syncthreads();
+#ifndef MPCQ_MFMA_SWEEPS
+  {   // vector-ALU form (see riccati_forward)
+    const Sel<TQ> sel(h);
+    const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
+    constexpr int PD = Depth<GAB>::PD;
+    const bool prow = c >= 10 && c < NX;
+    TQ xv[4], xc = S[dxo + c], qa[PD + 1][4], qz[PD + 1][4], qc[PD + 1];
+    vl_load(S + dxo, h, xv);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const int id = d < N ? d : N - 1;
+      rm.load(A, id, qa[d]);
+      vl_load(S + L.vin + id * VS, h, qz[d]);
+      qc[d] = A[L.c + id * VS + c];
+    }
+#pragma unroll MPCQ_UNROLL_SWEEP
+    for (int i = 0; i < N; ++i) {
+      const int ip = i + PD < N ? i + PD : N - 1;
+      rm.load(A, ip, qa[PD]);
+      vl_load(S + L.vin + ip * VS, h, qz[PD]);
+      qc[PD] = A[L.c + ip * VS + c];
+      TQ vB[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) vB[s] = sel.A[s] * xv[s] + sel.U[s] * qz[0][s];
+      const TQ t = hsum((qa[0][0] * vB[0] + qa[0][1] * vB[1]) + (qa[0][2] * vB[2] + qa[0][3] * vB[3]));
+      TQ xn = t + (prow ? xc : TQ(0)) + (with_c ? qc[0] : TQ(0));
+      xn = c < NX ? xn : TQ(0);
+      xc = xn;
+      if (lane < VS) S[dxo + (i + 1) * VS + lane] = xn;
+      __syncthreads();
+      vl_load(S + dxo + (i + 1) * VS, h, xv);
+      shift<TQ, PD>(qa); shift<TQ, PD>(qz);
+#pragma unroll
+      for (int d = 0; d < PD; ++d) qc[d] = qc[d + 1];
+    }
+    __syncthreads();
+    return;
+  }
+#endif
+  const bool vl = c == 14;
   const Sel<TQ> sel(h);
   const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
   constexpr int PD = Depth<GAB>::PD;
@@ -813,9 +852,46 @@ MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dx
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_COLD void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
-  const bool vl = c == 14;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
   __syncthreads();
+#ifndef MPCQ_MFMA_SWEEPS
+  {   // vector-ALU form (see riccati_forward): pi rides group-uniform in registers and lane-indexed through S[L.spv]
+    const KMaj<TQ> km(L, N, h, c);
+    constexpr int PD = Depth<GAB>::PD;
+    const bool arow = c < 10, prow = c >= 10 && c < NX;
+    const TQ qdc = S[L.wq + c];
+    TQ pc = S[L.wq + VS + c] * S[L.dx + N * VS + c] + A[L.qv + N * VS + c];
+    TQ pi[4], qa[PD + 1][4], qq[PD + 1];
+    if (lane < VS) S[L.spv + lane] = pc;
+    __syncthreads();
+    vl_load(S + L.spv, h, pi);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const int id = N - 1 - d > 0 ? N - 1 - d : 0;
+      km.load(A, id, qa[d]);
+      qq[d] = A[L.qv + id * VS + c];
+    }
+#pragma unroll MPCQ_UNROLL_SWEEP
+    for (int i = N - 1; i >= 0; --i) {
+      const int ip = i - PD > 0 ? i - PD : 0;
+      km.load(A, ip, qa[PD]);
+      qq[PD] = A[L.qv + ip * VS + c];
+      const TQ dxc = S[L.dx + i * VS + c], gvc = S[L.vin + i * VS + c];
+      const TQ t = hsum((qa[0][0] * pi[0] + qa[0][1] * pi[1]) + (qa[0][2] * pi[2] + qa[0][3] * pi[3]));   // (AB''^T pi)[c]
+      if (lane < VS) S[L.grad + i * VS + lane] = t + gvc;
+      pc = (arow ? t : (prow ? pc : TQ(0))) + (qdc * dxc + qq[0]);
+      if (lane < VS) S[L.spv + lane] = pc;
+      __syncthreads();
+      vl_load(S + L.spv, h, pi);
+      shift<TQ, PD>(qa);
+#pragma unroll
+      for (int d = 0; d < PD; ++d) qq[d] = qq[d + 1];
+    }
+    __syncthreads();
+    return;
+  }
+#endif
+  const bool vl = c == 14;
   const Sel<TQ> sel(h);
   const KMaj<TQ> km(L, N, h, c);
   constexpr int PD = Depth<GAB>::PD;
@@ -860,6 +936,42 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
+#ifndef MPCQ_MFMA_SWEEPS
+  {   // vector-ALU form (see riccati_forward): p rides group-uniform in registers and lane-indexed through S[L.spv]
+    const KMaj<TQ> km(L, N, h, c);
+    const int lj = lane < NU ? lane : 0;
+    constexpr int PD = Depth<GAB>::PD;
+    const bool arow = c < 10, prow = c >= 10 && c < NX;
+    TQ pv[4] = {0, 0, 0, 0}, pc = 0, qa[PD + 1][4];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) km.load(A, N - 1 - d > 0 ? N - 1 - d : 0, qa[d]);
+#pragma unroll MPCQ_UNROLL_SWEEP
+    for (int i = N - 1; i >= 0; --i) {
+      km.load(A, i - PD > 0 ? i - PD : 0, qa[PD]);
+      const TQ rvc = S[L.vin + i * VS + c];                    // rho_j on lane column 10 + j
+      const TQ kk = S[L.K + i * KS + h * ABW + c];             // K[h][c]
+      const V4<TQ> li = *reinterpret_cast<const V4<TQ>*>(S + L.Linv + i * 16 + lj * 4);
+      const TQ rtj = S[L.rt + i * NU + lj];
+      const TQ t = hsum((qa[0][0] * pv[0] + qa[0][1] * pv[1]) + (qa[0][2] * pv[2] + qa[0][3] * pv[3]));   // (AB''^T p)[c]
+      const TQ gt = t + rvc;                                   // gt_j = rho_j + (B^T p)_j on lane column 10 + j
+      TQ g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = bc(gt, 10 + j);
+      const TQ gh = h == 0 ? g[0] : (h == 1 ? g[1] : (h == 2 ? g[2] : g[3]));
+      pc = (arow ? t : (prow ? pc : TQ(0))) + hsum(kk * gh);   // p_i = A^T p_{i+1} + K^T gt (pinned rows of K are 0)
+      if (lane < VS) S[L.spv + lane] = pc;
+      if (lane < NU) {
+        const TQ kvj = -(li.a * g[0] + li.b * g[1] + li.c * g[2] + li.d * g[3]);
+        S[L.vin + i * VS + lane] = (polish && rtj < TQ(0)) ? TQ(0) : kvj;
+      }
+      __syncthreads();
+      vl_load(S + L.spv, h, pv);
+      shift<TQ, PD>(qa);
+    }
+    __syncthreads();
+    return;
+  }
+#endif
   const Sel<TQ> sel(h);
   const KMaj<TQ> km(L, N, h, c);
   const int lj = lane < NU ? lane : 0;
@@ -1045,7 +1157,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
   for (int i = lane; i < nv; i += 64) {
     const TQ rr = S[L.wq + 2 * VS + (i & 3)];
     TQ v;
-    if (!polish) v = rr + tdiv(S[L.ll + i], S[L.sl + i]) + tdiv(S[L.lu + i], S[L.su + i]);
+    if (!polish) v = rr + S[L.ll + i] * trcp(S[L.sl + i]) + S[L.lu + i] * trcp(S[L.su + i]);
     else v = S[L.act + i] != TQ(0) ? TQ(-1) : rr;
     S[L.rt + i] = v;
   }
@@ -1286,20 +1398,21 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const T
     PF_STOP(PF_FACTOR);
     if (!fok) { status = 4; break; }
     PF_START(); riccati_forward<C>(m, S, A, L, L.dza PF_PASS); PF_STOP(PF_FWD);
-    TQ aff = 1;
+    // Step lengths without divisions: alpha = min_i(-s_i / ds_i | ds_i < 0) = 1 / max_i(-ds_i / s_i), and every quotient by a
+    // slack or a multiplier is a product with its reciprocal (v_rcp_f64 + two Newton steps instead of the ~35-instruction
+    // IEEE division, 28 of which per input and iteration were 8 % of an iteration).
+    TQ ainv = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dl = -ll - tdiv(ll, sl) * d, du = -lu + tdiv(lu, su) * d;
-      if (d < 0) aff = tmin(aff, tdiv(-sl, d));
-      if (d > 0) aff = tmin(aff, tdiv(su, d));
-      if (dl < 0) aff = tmin(aff, tdiv(-ll, dl));
-      if (du < 0) aff = tmin(aff, tdiv(-lu, du));
+      const TQ rsl = trcp(sl), rsu = trcp(su);
+      const TQ dl = -ll - ll * rsl * d, du = -lu + lu * rsu * d;
+      ainv = tmax(ainv, tmax(tmax(-d * rsl, d * rsu), tmax(-dl * trcp(ll), -du * trcp(lu))));
     }
-    aff = wave_min(aff);
+    const TQ aff = trcp(wave_max(ainv));
     TQ mua = 0;
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dl = -ll - tdiv(ll, sl) * d, du = -lu + tdiv(lu, su) * d;
+      const TQ dl = -ll - ll * trcp(sl) * d, du = -lu + lu * trcp(su) * d;
       mua += (sl + aff * d) * (ll + aff * dl) + (su - aff * d) * (lu + aff * du);
     }
     mua = wave_sum(mua) / (2 * nv);
@@ -1308,45 +1421,41 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const T
     // corrector rhs r = -rd + rcl/sl - rcu/su ; linear term rho = -r
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dl = -ll - tdiv(ll, sl) * d, du = -lu + tdiv(lu, su) * d;
+      const TQ rsl = trcp(sl), rsu = trcp(su);
+      const TQ dl = -ll - ll * rsl * d, du = -lu + lu * rsu * d;
       const TQ rcl = -sl * ll + sigma * mu - d * dl;
       const TQ rcu = -su * lu + sigma * mu + d * du;
       const TQ rd = S[L.grad + GI(i)] - ll + lu;
-      S[L.rho + i] = rd - tdiv(rcl, sl) + tdiv(rcu, su);
+      S[L.rho + i] = rd - rcl * rsl + rcu * rsu;
     }
     __syncthreads();
     PF_START(); riccati_backward_vec<C>(m, S, A, L, false); PF_STOP(PF_BWD);
     PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
-    TQ ap = 1, ad = 1;
+    TQ apinv = 1, adinv = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dla = -ll - tdiv(ll, sl) * da, dua = -lu + tdiv(lu, su) * da;
+      const TQ rsl = trcp(sl), rsu = trcp(su);
+      const TQ dla = -ll - ll * rsl * da, dua = -lu + lu * rsu * da;
       const TQ rcl = -sl * ll + sigma * mu - da * dla;
       const TQ rcu = -su * lu + sigma * mu + da * dua;
-      const TQ dl = tdiv(rcl - ll * d, sl), du = tdiv(rcu + lu * d, su);
-      if (d < 0) ap = tmin(ap, tdiv(-sl, d));
-      if (d > 0) ap = tmin(ap, tdiv(su, d));
-      if (dl < 0) ad = tmin(ad, tdiv(-ll, dl));
-      if (du < 0) ad = tmin(ad, tdiv(-lu, du));
+      const TQ dl = (rcl - ll * d) * rsl, du = (rcu + lu * d) * rsu;
+      apinv = tmax(apinv, tmax(-d * rsl, d * rsu));
+      adinv = tmax(adinv, tmax(-dl * trcp(ll), -du * trcp(lu)));
+      S[L.act + i] = dl; S[L.rt + i] = du;   // kept for the update below (neither array is live inside an interior-point iteration here)
     }
-    ap = wave_min(ap);
-    ad = wave_min(ad);
     const TQ tau = tmax(TQ(0.995), 1 - mu);
-    ap = tmin(TQ(1), tau * ap);
-    ad = tmin(TQ(1), tau * ad);
+    // alpha = min(1, tau / max_i(...)): the maxima start at 1, i.e. an unrestricted step has length tau
+    TQ ap = tmin(TQ(1), tau * trcp(wave_max(apinv))), ad = tmin(TQ(1), tau * trcp(wave_max(adinv)));
     for (int i = tid; i < nv; i += 64) {
-      const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
-      const TQ dla = -ll - tdiv(ll, sl) * da, dua = -lu + tdiv(lu, su) * da;
-      const TQ rcl = -sl * ll + sigma * mu - da * dla;
-      const TQ rcu = -su * lu + sigma * mu + da * dua;
-      const TQ dl = tdiv(rcl - ll * d, sl), du = tdiv(rcu + lu * d, su);
+      const TQ d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
+      const TQ dl = S[L.act + i], du = S[L.rt + i];
       S[L.z + i] += ap * d; S[L.sl + i] = sl + ap * d; S[L.su + i] = su - ap * d;
       S[L.ll + i] = ll + ad * dl; S[L.lu + i] = lu + ad * du;
       // fp64: the gradient follows the step without a sweep.  The corrector solved (H + Sigma) dz = -rho with
       // Sigma = ll/sl + lu/su of this iteration, so H dz = -rho - Sigma dz elementwise (the solve leaves a residual at the
       // rounding level of double, far below the hand-over tolerance; the active-set iterations that follow recompute
       // everything).  fp32 keeps the adjoint sweep: there the residual of the solve would pile up in the gradient.
-      if (sizeof(TQ) == 8) S[L.grad + GI(i)] += ap * (-S[L.rho + i] - (tdiv(ll, sl) + tdiv(lu, su)) * d);
+      if (sizeof(TQ) == 8) S[L.grad + GI(i)] += ap * (-S[L.rho + i] - (ll * trcp(sl) + lu * trcp(su)) * d);
     }
     for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
     __syncthreads();
