@@ -323,6 +323,14 @@ __device__ inline double hsum(double v) {
   const u2 ql = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false), qh = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
   return __hiloint2double((int)qh[0], (int)ql[0]) + __hiloint2double((int)qh[1], (int)ql[1]);
 }
+// sum over the 16 lanes of a row, result on every lane of the row (DPP only)
+template <typename T> __device__ inline T rowsum(T v) {
+  v += dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp<0x124>(v);   // row_ror:4
+  v += dpp<0x128>(v);   // row_ror:8
+  return v;
+}
 // wave-wide reductions: butterfly inside each row of 16 with DPP, then the 4 row results through SGPRs
 template <typename T, typename OP> __device__ inline T wave_reduce(T v, OP op) {
   v = op(v, dpp<0xB1>(v));    // quad_perm [1,0,3,2]
@@ -348,6 +356,24 @@ __host__ __device__ inline int i2o(int k) { return k < 10 ? k + 3 : k - 10; }
 // back as the B operand of the next product (and a symmetric one as the A operand) without leaving
 // registers.  RI differs between the f32 and f64 instructions.
 template <typename TQ> __device__ inline int RI(int s, int h) { return sizeof(TQ) == 4 ? 4 * h + s : h + 4 * s; }
+// A vector held lane-indexed (lane (h,c) holds x[c], the same in every row h) -> group-uniform operand form (every lane of row
+// h holds x[RI(s,h)], s = 0..3) without LDS: rotate row h left by U*h lanes (two conditional row_ror; U = 1 for the f64 slot
+// map h + 4s, 4 for the f32 map 4h + s), then row_newbcast of the lane that now holds the slot.
+template <typename TQ> __device__ inline void l2g(TQ x, int h, TQ (&v)[4]) {
+  if (sizeof(TQ) == 8) {
+    const TQ r1 = dpp<0x12F>(x);            // row_ror:15 -> lane c <- lane c + 1
+    x = (h & 1) ? r1 : x;
+    const TQ r2 = dpp<0x12E>(x);            // row_ror:14 -> lane c <- lane c + 2
+    x = (h & 2) ? r2 : x;
+    v[0] = dpp<0x150>(x); v[1] = dpp<0x154>(x); v[2] = dpp<0x158>(x); v[3] = dpp<0x15C>(x);   // row_newbcast:0,4,8,12
+  } else {
+    const TQ r1 = dpp<0x12C>(x);            // row_ror:12 -> lane c <- lane c + 4
+    x = (h & 1) ? r1 : x;
+    const TQ r2 = dpp<0x128>(x);            // row_ror:8  -> lane c <- lane c + 8
+    x = (h & 2) ? r2 : x;
+    v[0] = dpp<0x150>(x); v[1] = dpp<0x151>(x); v[2] = dpp<0x152>(x); v[3] = dpp<0x153>(x);   // row_newbcast:0..3
+  }
+}
 #ifndef MPCQ_NO_MFMA
 __device__ inline void mfma(float (&acc)[4], float a, float b) {
   typedef float f4 __attribute__((ext_vector_type(4)));
@@ -428,7 +454,10 @@ template <typename TQ> struct RMaj {
 };
 // Operands are fetched PD stages ahead of their use: one stage hides the LDS latency, the global stage
 // records need more.  q[0] is the current stage; shift() retires it.
-template <bool GAB> struct Depth { static constexpr int PD = GAB ? 2 : 1; };
+#ifndef MPCQ_PD_GLOBAL
+#define MPCQ_PD_GLOBAL 2
+#endif
+template <bool GAB> struct Depth { static constexpr int PD = GAB ? MPCQ_PD_GLOBAL : 1; };
 template <typename TQ, int PD> __device__ inline void shift(TQ (&q)[PD + 1][4]) {
 #pragma unroll
   for (int d = 0; d < PD; ++d)
@@ -780,8 +809,7 @@ MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dx
     const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
     constexpr int PD = Depth<GAB>::PD;
     const bool prow = c >= 10 && c < NX;
-    TQ xv[4], xc = S[dxo + c], qa[PD + 1][4], qz[PD + 1][4], qc[PD + 1];
-    vl_load(S + dxo, h, xv);
+    TQ xc = S[dxo + c], qa[PD + 1][4], qz[PD + 1][4], qc[PD + 1];
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
       const int id = d < N ? d : N - 1;
@@ -795,7 +823,8 @@ MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dx
       rm.load(A, ip, qa[PD]);
       vl_load(S + L.vin + ip * VS, h, qz[PD]);
       qc[PD] = A[L.c + ip * VS + c];
-      TQ vB[4];
+      TQ xv[4], vB[4];
+      l2g<TQ>(xc, h, xv);
 #pragma unroll
       for (int s = 0; s < 4; ++s) vB[s] = sel.A[s] * xv[s] + sel.U[s] * qz[0][s];
       const TQ t = hsum((qa[0][0] * vB[0] + qa[0][1] * vB[1]) + (qa[0][2] * vB[2] + qa[0][3] * vB[3]));
@@ -803,8 +832,6 @@ MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dx
       xn = c < NX ? xn : TQ(0);
       xc = xn;
       if (lane < VS) S[dxo + (i + 1) * VS + lane] = xn;
-      __syncthreads();
-      vl_load(S + dxo + (i + 1) * VS, h, xv);
       shift<TQ, PD>(qa); shift<TQ, PD>(qz);
 #pragma unroll
       for (int d = 0; d < PD; ++d) qc[d] = qc[d + 1];
@@ -855,16 +882,13 @@ MPCQ_COLD void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
   __syncthreads();
 #ifndef MPCQ_MFMA_SWEEPS
-  {   // vector-ALU form (see riccati_forward): pi rides group-uniform in registers and lane-indexed through S[L.spv]
+  {   // vector-ALU form (see riccati_forward)
     const KMaj<TQ> km(L, N, h, c);
     constexpr int PD = Depth<GAB>::PD;
     const bool arow = c < 10, prow = c >= 10 && c < NX;
     const TQ qdc = S[L.wq + c];
     TQ pc = S[L.wq + VS + c] * S[L.dx + N * VS + c] + A[L.qv + N * VS + c];
-    TQ pi[4], qa[PD + 1][4], qq[PD + 1];
-    if (lane < VS) S[L.spv + lane] = pc;
-    __syncthreads();
-    vl_load(S + L.spv, h, pi);
+    TQ qa[PD + 1][4], qq[PD + 1];
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
       const int id = N - 1 - d > 0 ? N - 1 - d : 0;
@@ -877,12 +901,11 @@ MPCQ_COLD void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
       km.load(A, ip, qa[PD]);
       qq[PD] = A[L.qv + ip * VS + c];
       const TQ dxc = S[L.dx + i * VS + c], gvc = S[L.vin + i * VS + c];
+      TQ pi[4];
+      l2g<TQ>(pc, h, pi);
       const TQ t = hsum((qa[0][0] * pi[0] + qa[0][1] * pi[1]) + (qa[0][2] * pi[2] + qa[0][3] * pi[3]));   // (AB''^T pi)[c]
       if (lane < VS) S[L.grad + i * VS + lane] = t + gvc;
       pc = (arow ? t : (prow ? pc : TQ(0))) + (qdc * dxc + qq[0]);
-      if (lane < VS) S[L.spv + lane] = pc;
-      __syncthreads();
-      vl_load(S + L.spv, h, pi);
       shift<TQ, PD>(qa);
 #pragma unroll
       for (int d = 0; d < PD; ++d) qq[d] = qq[d + 1];
@@ -937,12 +960,12 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
 #ifndef MPCQ_MFMA_SWEEPS
-  {   // vector-ALU form (see riccati_forward): p rides group-uniform in registers and lane-indexed through S[L.spv]
+  {   // vector-ALU form (see riccati_forward)
     const KMaj<TQ> km(L, N, h, c);
     const int lj = lane < NU ? lane : 0;
     constexpr int PD = Depth<GAB>::PD;
     const bool arow = c < 10, prow = c >= 10 && c < NX;
-    TQ pv[4] = {0, 0, 0, 0}, pc = 0, qa[PD + 1][4];
+    TQ pc = 0, qa[PD + 1][4];
 #pragma unroll
     for (int d = 0; d < PD; ++d) km.load(A, N - 1 - d > 0 ? N - 1 - d : 0, qa[d]);
 #pragma unroll MPCQ_UNROLL_SWEEP
@@ -952,20 +975,25 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
       const TQ kk = S[L.K + i * KS + h * ABW + c];             // K[h][c]
       const V4<TQ> li = *reinterpret_cast<const V4<TQ>*>(S + L.Linv + i * 16 + lj * 4);
       const TQ rtj = S[L.rt + i * NU + lj];
+      TQ pv[4];
+      l2g<TQ>(pc, h, pv);
       const TQ t = hsum((qa[0][0] * pv[0] + qa[0][1] * pv[1]) + (qa[0][2] * pv[2] + qa[0][3] * pv[3]));   // (AB''^T p)[c]
       const TQ gt = t + rvc;                                   // gt_j = rho_j + (B^T p)_j on lane column 10 + j
+      // row h needs gt_h on every lane: rotate row h left by h lanes, broadcast lane 10
+      TQ r = gt;
+      const TQ r1 = dpp<0x12F>(r);
+      r = (h & 1) ? r1 : r;
+      const TQ r2 = dpp<0x12E>(r);
+      r = (h & 2) ? r2 : r;
+      const TQ gh = dpp<0x15A>(r);
+      pc = (arow ? t : (prow ? pc : TQ(0))) + hsum(kk * gh);   // p_i = A^T p_{i+1} + K^T gt (pinned rows of K are 0)
       TQ g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = bc(gt, 10 + j);
-      const TQ gh = h == 0 ? g[0] : (h == 1 ? g[1] : (h == 2 ? g[2] : g[3]));
-      pc = (arow ? t : (prow ? pc : TQ(0))) + hsum(kk * gh);   // p_i = A^T p_{i+1} + K^T gt (pinned rows of K are 0)
-      if (lane < VS) S[L.spv + lane] = pc;
       if (lane < NU) {
         const TQ kvj = -(li.a * g[0] + li.b * g[1] + li.c * g[2] + li.d * g[3]);
         S[L.vin + i * VS + lane] = (polish && rtj < TQ(0)) ? TQ(0) : kvj;
       }
-      __syncthreads();
-      vl_load(S + L.spv, h, pv);
       shift<TQ, PD>(qa);
     }
     __syncthreads();
@@ -1021,50 +1049,55 @@ template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB
 MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
 #ifndef MPCQ_MFMA_SWEEPS
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
+  constexpr bool F64 = sizeof(TQ) == 8;
   const Sel<TQ> sel(h);
-  const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c), rk(L.zb, L.K, KS, NU, h, c);
+  const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
   constexpr int PD = Depth<GAB>::PD;
   const int xo = affine ? L.dx : L.Dx;
   const bool prow = c >= 10 && c < NX;   // position rows: identity block of [A|B]
-  TQ xv[4] = {0, 0, 0, 0}, xc = 0, qa[PD + 1][4], kc[4], kn[4], kv, kvn, gc = 0, gcn = 0;
-  if (affine) { vl_load(S + L.dx, h, xv); xc = S[L.dx + c]; gc = S[L.Dx + c]; }
+  // Input slots 10 + j of the operand held by lane row h: f64 (slot = h + 4s) one per row -- register 2 (h >= 2) or 3, input
+  // (h + 2) & 3; f32 (slot = 4h + s) two in rows 2 and 3 -- registers 2,3 / 0,1, inputs 0,1 / 2,3.  Row h computes just those
+  // dz_j = K_j . Dx + k_j itself, from the lane-indexed Dx (K row j lane-indexed, sum over the row): no broadcast of dz at all.
+  const int j0 = F64 ? ((h + 2) & 3) : (h == 3 ? 2 : 0), j1 = F64 ? j0 : j0 + 1;
+  const bool hasu = F64 || h >= 2;
+  const int ko0 = L.K + j0 * ABW + c, ko1 = L.K + j1 * ABW + c;
+  TQ xc = 0, qa[PD + 1][4], k0, k1 = 0, g0, g1 = 0, gc = 0, gcn = 0;
+  if (affine) { xc = S[L.dx + c]; gc = S[L.Dx + c]; }
   else if (lane < VS) S[L.Dx + lane] = 0;
 #pragma unroll
   for (int d = 0; d < PD; ++d) rm.load(A, d < N ? d : N - 1, qa[d]);
-  rk.load(S, 0, kc);
-  kv = S[L.vin + c];
+  k0 = S[ko0]; g0 = S[L.vin + j0];
+  if (!F64) { k1 = S[ko1]; g1 = S[L.vin + j1]; }
 #pragma unroll MPCQ_UNROLL_SWEEP
   for (int i = 0; i < N; ++i) {
     const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1;
     rm.load(A, ig, qa[PD]);
-    rk.load(S, ip, kn);
-    kvn = S[L.vin + ip * VS + c];
+    const TQ k0n = S[ko0 + ip * KS], g0n = S[L.vin + ip * VS + j0];
+    TQ k1n = 0, g1n = 0;
+    if (!F64) { k1n = S[ko1 + ip * KS]; g1n = S[L.vin + ip * VS + j1]; }
     if (affine) gcn = S[L.Dx + ip * VS + c];
     PF_FINE(11);
-    // dz = K Dx + k: lanes (., c < 4)
-    TQ t = (kc[0] * xv[0] + kc[1] * xv[1]) + (kc[2] * xv[2] + kc[3] * xv[3]);
-    // the state part of the second product does not wait for dz
-    TQ ta = (qa[0][0] * (sel.A[0] * xv[0]) + qa[0][1] * (sel.A[1] * xv[1])) + (qa[0][2] * (sel.A[2] * xv[2]) + qa[0][3] * (sel.A[3] * xv[3]));
-    const TQ u = hsum(t) + kv;
+    const TQ u0 = rowsum(k0 * xc) + g0;
+    TQ u1 = 0;
+    if (!F64) u1 = rowsum(k1 * xc) + g1;
     PF_FINE(12);
-    if (lane < NU) S[dzo + i * NU + lane] = u;
-    TQ d[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) d[j] = bc(u, j);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (h == in_h<TQ>(j)) ta += qa[0][in_s<TQ>(j)] * d[j];
+    TQ xv[4];
+    l2g<TQ>(xc, h, xv);
+    TQ ta = (qa[0][0] * (sel.A[0] * xv[0]) + qa[0][1] * (sel.A[1] * xv[1])) + (qa[0][2] * (sel.A[2] * xv[2]) + qa[0][3] * (sel.A[3] * xv[3]));
     PF_FINE(13);
+    if (F64) {
+      ta += (h >= 2 ? qa[0][2] : qa[0][3]) * u0;
+      if (c == 0) S[dzo + i * NU + j0] = u0;
+    } else {
+      if (hasu) ta += (h == 2 ? qa[0][2] : qa[0][0]) * u0 + (h == 2 ? qa[0][3] : qa[0][1]) * u1;
+      if (c == 0 && hasu) { S[dzo + i * NU + j0] = u0; S[dzo + i * NU + j1] = u1; }
+    }
     TQ xn = hsum(ta) + (prow ? xc : TQ(0)) + (affine ? gc : TQ(0));
     xn = c < NX ? xn : TQ(0);
     PF_FINE(14);
     xc = xn;
     if (lane < VS) S[xo + (i + 1) * VS + lane] = xn;
-    __syncthreads();
-    vl_load(S + xo + (i + 1) * VS, h, xv);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kc[s] = kn[s];
-    kv = kvn; gc = gcn;
+    k0 = k0n; g0 = g0n; k1 = k1n; g1 = g1n; gc = gcn;
     shift<TQ, PD>(qa);
   }
   __syncthreads();

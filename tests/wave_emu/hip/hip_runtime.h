@@ -110,7 +110,7 @@ typedef float emu_f4 __attribute__((ext_vector_type(4)));
 typedef double emu_d4 __attribute__((ext_vector_type(4)));
 inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f4 c, int, int, int) { return emu_mfma<float, emu_f4, false>(a, b, c); }
 inline emu_d4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emu_d4 c, int, int, int) { return emu_mfma<double, emu_d4, true>(a, b, c); }
-// DPP: quad_perm (ctrl 0x00..0xFF) and row_ror:n (0x121..0x12F) with all rows/banks enabled
+// DPP: quad_perm (ctrl 0x00..0xFF), row_ror:n (0x121..0x12F) and row_newbcast:n (0x150..0x15F) with all rows/banks enabled
 inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool) {
   (void)old;
   uint64_t* ex = emu::exchange();
@@ -120,6 +120,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool)
   unsigned src;
   if (ctrl <= 0xFF) src = (t & ~3u) | ((unsigned)(ctrl >> (2 * (t & 3))) & 3u);
   else if (ctrl >= 0x121 && ctrl <= 0x12F) src = (t & ~15u) | ((t - (unsigned)(ctrl - 0x120)) & 15u);
+  else if (ctrl >= 0x150 && ctrl <= 0x15F) src = (t & ~15u) | (unsigned)(ctrl - 0x150);   // row_newbcast:n (gfx90a+)
   else { std::abort(); }
   const int r = (int)(uint32_t)ex[src];
   emu::sync();
