@@ -109,7 +109,10 @@ int mpcq_get_x(mpcq_engine* e, int32_t stage, double* out);      /* .get(stage,'
 int mpcq_get_u(mpcq_engine* e, int32_t stage, double* out);      /* .get(stage,'u') -> [B,4]  */
 int mpcq_get_cost(mpcq_engine* e, double* out);                  /* .get_cost()     -> [B]    */
 int mpcq_get_status(mpcq_engine* e, int32_t* out);               /* solve() status  -> [B]    */
-int mpcq_get_qp_iter(mpcq_engine* e, int32_t* out);              /* IPM iterations  -> [B]    */
+int mpcq_get_qp_iter(mpcq_engine* e, int32_t* out);              /* -> [B]: Riccati factorisations of the last solve (active-set passes +
+                                                                     interior-point iterations); + 1000 when the warm active-set attempt was given
+                                                                     up for the interior point; + 10000 when that solve also moved more than two
+                                                                     inputs on/off their bounds (the next solve then skips the warm attempt)   */
 /* .get_stats('time_tot'): device time of the last solve/step launch in seconds (whole batch) */
 int mpcq_get_stats(mpcq_engine* e, double* time_tot);
 

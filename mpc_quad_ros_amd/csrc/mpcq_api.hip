@@ -267,6 +267,11 @@ struct EngineT : mpcq_engine {
     if (const char* t = getenv("MPCQ_IPM_MU0")) m.ipm_mu0 = (T)atof(t);
     m.warm_retry = 1;
     if (const char* t = getenv("MPCQ_WARM_RETRY")) m.warm_retry = atoi(t);
+    // a fallback solve whose solution changed more than this many bound states against the previous one marks a quadrotor whose
+    // saturated inputs flip between rotors every period: its next solve goes to the interior point directly (bench workload,
+    // lockstep: off 2.15 M steps/s, 8 -> 2.24, 4 -> 2.28, 2 -> 2.28)
+    m.flip_max = 2;
+    if (const char* t = getenv("MPCQ_FLIP_MAX")) m.flip_max = atoi(t);
     m.pdas_max = 0;   // passes in which pins and releases may happen together (fp64 active-set method; measured on the bench workload: such passes are rare, 0.2 % of the quadrotor-steps, and the multiplier evaluations they need cost 4 % of the launch time)
     if (const char* t = getenv("MPCQ_PDAS")) m.pdas_max = atoi(t);
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;

@@ -128,6 +128,7 @@ template <typename TQ>
 struct DevModel {
   int N, nb, skip, Tmax, B, qp_max_iter, polish_max, warm_max;
   int warm_retry; // cap of the warm attempt in the period after one that fell back to the interior point
+  int flip_max;   // more changed bound states than this in a fallback solve: the next period skips the warm attempt (< 0: never)
   int pdas_max;   // passes in which wrong-signed multipliers are released even at an infeasible minimiser (0: primal rule only)
   int gab;   // stage records (AB'', c, qv) live in DevState::stage instead of LDS (must match the kernel instantiation)
   double h, dt_pred;
@@ -1893,7 +1894,12 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
   // active-set attempt; the first period in which the short attempt succeeds restores the full budget.
   // phase: 0 = everything inside this launch; MODE_DEFER = give the interior-point solve away (returns -1);
   //        MODE_FINISH = the interior point comes from the dense kernel (rec), continue behind it
-  const int warm_cap = prev_iter >= 1000 ? m.warm_retry : m.warm_max;
+  // prev_iter >= 10000: the previous solve fell back AND its solution differed from the one before in more than flip_max
+  // bound states -- a quadrotor whose saturated inputs flip between rotors from period to period (infeasible references,
+  // near-degenerate QPs): the previous working set is no guess at all there, the warm attempt is skipped altogether.
+  const bool flipping = m.flip_max >= 0 && prev_iter >= 10000;
+  const int warm_cap = flipping ? 0 : (prev_iter % 10000 >= 1000 ? m.warm_retry : m.warm_max);
+  if (flipping) wpasses = 1000;   // counts as a fallback solve
   if (phase != MODE_FINISH && prev_iter > 0 && warm_cap > 0) {
     if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap PF_PASS)
                         : polish_incremental<C>(m, S, A, L, gm, wpasses, true, warm_cap PF_PASS)) {   // sets z = 0 and its own gradient scale
@@ -1957,7 +1963,17 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
   }
   if (need_roll) { PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
   *status = st;
-  return it + passes + wpasses;
+  // bound states that differ between the previous solution (z = 0: on a bound where lb or ub is 0) and this one
+  int chg = 0;
+  if (m.flip_max >= 0 && prev_iter > 0) {
+    for (int i = tid; i < nv; i += 64) {
+      const TQ lb = S[L.lb + i], ub = S[L.ub + i], z = S[L.z + i];
+      const int was = lb == TQ(0) ? -1 : (ub == TQ(0) ? 1 : 0), is = z == lb ? -1 : (z == ub ? 1 : 0);
+      chg += was != is ? 1 : 0;
+    }
+    chg = wave_sum(chg);
+  }
+  return it + passes + wpasses + (m.flip_max >= 0 && chg > m.flip_max ? 10000 : 0);
 }
 
 // ------------------------------------------------------------------ RGP regress (3 axes, one new point each)
