@@ -140,6 +140,7 @@ struct DevModel {
   TQ qp_tol;    // final KKT tolerance (IPM-only fallback)
   TQ ipm_tol;   // IPM -> active-set polish hand-over tolerance
   TQ ipm_margin;   // interior start: distance from the bounds in units of their width
+  TQ pin_ratio;    // working set taken over from the interior point: input pinned where multiplier > pin_ratio x slack
   TQ ipm_mu0;   // initial complementarity of the interior start, in units of the gradient scale
   TQ eps;       // unit roundoff scale of TQ used for KKT sign / bound tests
   TQ L2inv[3], sf2[3], sn2[3];
@@ -1513,7 +1514,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
     }
   } else {      // working set identified by the interior point
     for (int i = tid; i < nv; i += 64)
-      S[L.act + i] = S[L.ll + i] > S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > S[L.su + i] ? TQ(1) : TQ(0));
+      S[L.act + i] = S[L.ll + i] > m.pin_ratio * S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > m.pin_ratio * S[L.su + i] ? TQ(1) : TQ(0));
   }
   __syncthreads();
   TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
@@ -1730,7 +1731,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
     }
   } else {      // working set identified by the interior point
     for (int i = tid; i < nv; i += 64)
-      S[L.act + i] = S[L.ll + i] > S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > S[L.su + i] ? TQ(1) : TQ(0));
+      S[L.act + i] = S[L.ll + i] > m.pin_ratio * S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > m.pin_ratio * S[L.su + i] ? TQ(1) : TQ(0));
   }
   __syncthreads();
   TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
