@@ -129,6 +129,7 @@ struct DevModel {
   int N, nb, skip, Tmax, B, qp_max_iter, polish_max, warm_max;
   int warm_retry; // cap of the warm attempt in the period after one that fell back to the interior point
   int flip_max;   // more changed bound states than this in a fallback solve: the next period skips the warm attempt (< 0: never)
+  int abort_pins; // warm attempt given up after its first pass when that pins at least this many inputs (0: never)
   int pdas_max;   // passes in which wrong-signed multipliers are released even at an infeasible minimiser (0: primal rule only)
   int gab;   // stage records (AB'', c, qv) live in DevState::stage instead of LDS (must match the kernel instantiation)
   double h, dt_pred;
@@ -1706,6 +1707,9 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
     // a bulk release that bounces back wholesale with most of the inputs saturated: far from the optimal working set,
     // the interior point gets there faster
     if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) return false;
+    // the first minimiser of a warm attempt leaves the box in many inputs at once: the previous working set is no guess (the
+    // saturated inputs moved to other rotors); passes would follow one another, the interior point gets there faster
+    if (warm && passes == 0 && m.abort_pins > 0 && nblk >= m.abort_pins) return false;
     if (bounce && careful < 3) careful += 1;   // an input released in the previous pass is pinned again
     released = any_release;
     relmask = relnow;
