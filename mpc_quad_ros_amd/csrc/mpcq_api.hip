@@ -264,7 +264,9 @@ struct EngineT : mpcq_engine {
     // the weakly active inputs (multiplier ~ slack ~ sqrt(mu)) are pinned at once instead of costing a pinning pass later; wrongly
     // pinned ones are released by the multiplier check of the same pass (bench workload, lockstep: 10 -> 2.16 M steps/s,
     // 1 -> 2.28, 0.3 -> 2.35, 0.2 -> 2.37, 0.1 -> 2.36, 0.05 -> 2.31, 0.01 -> 2.21)
-    m.pin_ratio = (T)0.2;
+    // fp32 keeps 1: its multiplier sign test cannot tell a wrongly pinned weakly active input from a rightly pinned one, and the
+    // solve would end on a neighbouring vertex (worst control deviation on the tumbling reference log 1.2e-3 -> 4.1e-2)
+    m.pin_ratio = f32 ? (T)1 : (T)0.2;
     if (const char* t = getenv("MPCQ_PIN_RATIO")) m.pin_ratio = (T)atof(t);
     // complementarity of the interior start in units of the gradient scale.  The start is the previous solution pushed inside the
     // box, i.e. close to the new optimum: a small value makes it a warm start (measured, bench workload, fp64 lockstep:

@@ -53,9 +53,11 @@ def throughput(name, precision):
 
 rows = []
 for label, name, precision in [("fp64", "product", 0), ("fp32", "product", 1), ("fp32 arithmetic, bf16 storage of records + RGP state", "bf16", 1),
-                               ("fp64, matrix cores off", "nomfma", 0), ("fp32, matrix cores off", "nomfma", 1)]:
+                               ("fp64, matrix cores off", "nomfma", 0), ("fp32, matrix cores off", "nomfma", 1),
+                               ("fp64, sweeps as tiles on the matrix cores", "mfmasweeps", 0), ("fp32, sweeps as tiles on the matrix cores", "mfmasweeps", 1)]:
     if name != "product" and not os.path.exists(lib(name)):
         print("skip", label, "(build missing)"); continue
+    os.environ["MPCQ_PIN_RATIO"] = "1" if precision == 1 else "0.2"   # the defaults, spelled out: variant builds may predate them
     r = dict(config=label, N=N, nb=NB)
     r["parity"] = parity(name, precision) if BP else None
     r["throughput"] = throughput(name, precision) if BT else None
