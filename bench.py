@@ -362,7 +362,7 @@ def main():
                                     "kernel_avg_ms": 1e3 * k2 / max(l2, 1),
                                     "note": "same workload with the QP arithmetic in the other precision.  f32 (all-LDS working set): relative control "
                                             "deviation vs the fp64 oracle <= 1e-4 on every warm-started solve of the six reference logs (median 2e-6); "
-                                            "interior-point fallback solves reach 1.2e-4..3.2e-4 on two logs and 1.4e-3 on one tumbling step "
+                                            "interior-point fallback solves reach 1.2e-4..1.5e-4 on two logs and 1.2e-3 on one tumbling step "
                                             "(profiles/r2_f32_log_report.json, DESIGN.md section 5).  f64 (stage records in global memory): <= 3e-10.  "
                                             "Both place 4 quadrotors per CU"}
             e2.close()
