@@ -123,6 +123,11 @@ __device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __
 #else
 #define PF_FINE(k)
 #endif
+#if defined(MPCQ_PROFILE) && defined(MPCQ_PROFILE_FAC)   // cycle stamps inside a factorisation stage (slots 11..15)
+#define PF_FAC(k) pf_stop(pf, k)
+#else
+#define PF_FAC(k)
+#endif
 
 template <typename TQ>
 struct DevModel {
@@ -1184,7 +1189,7 @@ MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& 
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ* gscale = nullptr, TQ* mrows = nullptr,
+MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L PF_ARG, TQ* gscale = nullptr, TQ* mrows = nullptr,
                                       TQ* pstore = nullptr, int start = -1) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
@@ -1247,6 +1252,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
   __syncthreads();
 #pragma unroll MPCQ_UNROLL_FACTOR
   for (int i = first; i >= 0; --i) {
+    PF_FAC(15);                          // (loop overhead, P update tail of the previous stage)
     km.load(A, i > 0 ? i - 1 : 0, nxt);   // a factorisation stage is long enough to hide one global fetch
     if (affine) with_gap(i > 0 ? i - 1 : 0, nxt);
     TQ qvi = 0;
@@ -1260,6 +1266,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
     for (int s = 0; s < 4; ++s) { vs[s] = affine ? pv[s] + acc1[s] : pv[s]; b2[s] = vl ? vs[s] : acc1[s]; }
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc2, cur[s], b2[s]);               // F'' ; column 14 = AB''^T p
+    PF_FAC(11);                          // two tile products (8 MFMA)
     // hand rows 10..13 over to the stage-Hessian lanes through LDS
     if (sizeof(TQ) == 4) {
       if (h >= 2) {   // h = 2: registers 2,3 = rows 10,11 ; h = 3: registers 0,1 = rows 12,13
@@ -1310,6 +1317,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 #pragma unroll
           for (int q = 0; q < a; ++q) Lm[a][q] *= mk[a] * mk[q];
       }
+      PF_FAC(12);                        // LDS hand-over + operand reads
       // LDL^T (no square roots; the reciprocal pivots are the only long-latency operations of the chain):
       // Lm[a][q] (a > q) becomes the unit-lower factor, cm the unscaled column entries l*d
       TQ id[4], cm[4][4];
@@ -1330,6 +1338,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
           Lm[a][cc] = s2 * id[cc];
         }
       }
+      PF_FAC(13);                        // 4x4 LDL^T
       // rhs: M[:,b] for lanes < 13 (b < 10: F''[10+j][b]; position b = 10+t: T1''[10+t][10+j]), e_j for lanes 13..16
       TQ y[4], g[4];
 #pragma unroll
@@ -1377,6 +1386,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
         S[(lane < NX ? L.spv + lane : L.vin + i * VS + vj)] = ex;
       }
     }
+    PF_FAC(14);                          // right-hand sides, substitutions, stores of K, Lambda^-1, p
     if (i == 0) break;
     __syncthreads();
     // ---- P_i = Q + G + M^T K as one k=4 tile on top of the assembled C operand
@@ -1430,7 +1440,7 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const T
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    const bool fok = riccati_factor<C, false>(m, S, A, L);
+    const bool fok = riccati_factor<C, false>(m, S, A, L PF_PASS);
     PF_STOP(PF_FACTOR);
     if (!fok) { status = 4; break; }
     PF_START(); riccati_forward<C>(m, S, A, L, L.dza PF_PASS); PF_STOP(PF_FWD);
@@ -1576,11 +1586,11 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
       __syncthreads();
       PF_START();
       TQ gfac = 0;
-#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD)
+#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD) && !defined(MPCQ_PROFILE_FAC)
       pf.acc[13] += (keep_p && top >= 0 && top < N - 1) ? top + 1 : N;   // stages this factorisation visits
       pf.acc[14] += 1;                                                    // factorisations
 #endif
-      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac, nact > 0 ? G + L.mrow : nullptr, keep_p ? G + L.pst : nullptr, top);
+      const bool fok = riccati_factor<C, true, true>(m, S, A, L PF_PASS, &gfac, nact > 0 ? G + L.mrow : nullptr, keep_p ? G + L.pst : nullptr, top);
       top = -1;
       PF_STOP(PF_FACTOR);
       if (!fok) return false;
@@ -1698,7 +1708,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) printf("     pass %d feasible %d nblk %d release %d\n", passes, (int)feasible, nblk, (int)any_release);
 #endif
-#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD)
+#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD) && !defined(MPCQ_PROFILE_FAC)
     pf.acc[11] += nblk;                        // inputs pinned
     pf.acc[12] += any_release ? 1 : 0;         // passes with a release
     pf.acc[15] += (any_release && nblk > 0) ? 1 : 0;   // passes with both
@@ -1763,7 +1773,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
       __syncthreads();
       PF_START();
       TQ gfac = 0;
-      const bool fok = riccati_factor<C, true, true>(m, S, A, L, &gfac);
+      const bool fok = riccati_factor<C, true, true>(m, S, A, L PF_PASS, &gfac);
       PF_STOP(PF_FACTOR);
       if (!fok) return false;
       gm = tmax(TQ(1), gfac);
@@ -1836,7 +1846,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, L); PF_STOP(PF_FACTOR); if (!fok) return false; }
+    if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, L PF_PASS); PF_STOP(PF_FACTOR); if (!fok) return false; }
     else { riccati_backward_vec<C>(m, S, A, L, true); PF_STOP(PF_BWD); }
     refactor = false;
     PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);

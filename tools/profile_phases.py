@@ -15,6 +15,8 @@ from mpc_quad_ros_amd.trajectories import swarm_trajectories  # noqa: E402
 
 NAMES = ["load", "shoot_x", "shoot_s", "factor", "fwd", "bwd", "adjoint", "rollout", "update", "post", "total"]
 FINE = {11: "fwd: loads/shift", 12: "fwd: K Dx chain", 13: "fwd: broadcast", 14: "fwd: A Dx chain"}
+if os.environ.get("PROF_MODE") == "fac":   # library built with PROF_EXTRA=-DMPCQ_PROFILE_FAC: slots 11..15 split the factorisation
+    FINE = {11: "fac: tile products", 12: "fac: LDS hand-over", 13: "fac: 4x4 LDL^T", 14: "fac: solves + stores", 15: "fac: P update + loop"}
 
 
 def main():
@@ -46,8 +48,8 @@ def main():
         print(f"{n:10s} {mean[i]:12.0f} {100 * mean[i] / mean[10]:6.1f}% {mxs[i]:20.0f}")
     for k, n in FINE.items():
         if mean[k] > 0:
-            print(f"  {n:18s} {mean[k]:12.0f}")
-    if mean[14] > 0:   # active-set statistics of the fp64 path (diagnostic counters of polish())
+            print(f"  {n:22s} {mean[k]:12.0f} {mxs[k]:20.0f}")
+    if mean[14] > 0 and os.environ.get("PROF_MODE") != "fac":   # active-set statistics of the fp64 path (diagnostic counters of polish())
         tot = acc.sum(axis=0)
         print(f"factorisations per quad-step {mean[14]:.3f} (slowest quad of a launch: {mxs[14]:.2f}); stages visited per factorisation {tot[13] / tot[14]:.1f}; "
               f"pins per quad-step {mean[11]:.3f}, passes with a release {mean[12]:.3f}, with both {mean[15]:.3f}")
