@@ -282,7 +282,7 @@ struct EngineT : mpcq_engine {
     if (const char* t = getenv("MPCQ_FLIP_MAX")) m.flip_max = atoi(t);
     // (bench workload, lockstep: never -> 2.37 M steps/s, 8 -> 2.44, 6 -> 2.48, 5 -> 2.47, 4 -> 2.45, 3 -> 2.44; a rule on the pins +
     // releases accumulated over the passes added nothing)
-    m.abort_pins = 6;
+    m.abort_pins = N > 20 ? (3 * N) / 10 : 6;   // measured at N = 20; longer horizons in proportion
     if (const char* t = getenv("MPCQ_ABORT_PINS")) m.abort_pins = atoi(t);
     m.pdas_max = 0;   // passes in which pins and releases may happen together (fp64 active-set method; measured on the bench workload: such passes are rare, 0.2 % of the quadrotor-steps, and the multiplier evaluations they need cost 4 % of the launch time)
     if (const char* t = getenv("MPCQ_PDAS")) m.pdas_max = atoi(t);

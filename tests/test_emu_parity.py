@@ -50,7 +50,18 @@ def test_emu_saturating_references_many_working_sets():
     assert failed == 0
     print("saturating references: worst", worst, "passes", dict(sorted(hist.items())))
     assert worst < 1e-7
-    assert any(2 <= v < 1000 for v in hist) and any(v >= 1000 for v in hist)   # multi-pass warm attempts AND fallbacks were exercised
+    assert any(1000 <= v < 10000 for v in hist) and any(v >= 10000 for v in hist)   # fallbacks AND the direct interior-point solves of flipping quadrotors
+
+
+def test_emu_saturating_references_long_warm_attempts(monkeypatch):
+    """The same references with the early exits of the warm active-set attempt switched off: many-pass attempts (pins and
+    releases over several factorisations) end on the same optimum."""
+    monkeypatch.setenv("MPCQ_ABORT_PINS", "0"); monkeypatch.setenv("MPCQ_FLIP_MAX", "-1")
+    monkeypatch.setenv("MPCQ_WARM_MAX", "14"); monkeypatch.setenv("MPCQ_WARM_RETRY", "14")
+    worst, hist, failed = pc.case_saturating_references(make, B=2, K=14)
+    print("saturating references, long warm attempts: worst", worst, "passes", dict(sorted(hist.items())))
+    assert failed == 0 and worst < 1e-7
+    assert sum(n for v, n in hist.items() if 3 <= v <= 14) >= 4
 
 
 def test_emu_lane_order_independent(monkeypatch):
