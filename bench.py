@@ -89,11 +89,12 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(N, nb, seed, budget_s=18.0, refs=None):
-    """The fp64 CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload (same trajectories, same
-    pre-rolled regime is not reproduced: the sample starts at hover and runs closed loop), swept over OpenMP team
-    sizes {1, physical cores, all hardware threads}; the best is `value`, the single-thread figure rides along.
-    Reported next to the GPU number; not the thing measured or shipped."""
+def cpu_baseline(N, nb, seed, budget_s=18.0, refs=None, start=None):
+    """The fp64 CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload: the first quadrotors of the GPU
+    run, same references, continued closed loop from the state the GPU run ended in (`start`: iterate, RGP state, cursors
+    and plant states after pre-roll + warm-up + timed steps, to within one control period -- the same stationary mix of
+    flights, saturated quadrotors included; without `start` the sample begins at hover).  Swept over OpenMP team sizes; the best is `value`, the
+    single-thread figure rides along.  Reported next to the GPU number; not the thing measured or shipped."""
     from oracle.oracle import OracleEngine
     logical, phys = os.cpu_count() or 1, physical_cores()
     try:
@@ -124,7 +125,12 @@ def cpu_baseline(N, nb, seed, budget_s=18.0, refs=None):
         else:
             traj, lens = workload(seed, 0, B, 500)
         o.set_trajectories(traj, lens)
-        x = np.tile(X0, (B, 1))
+        from_start = start is not None and refs is not None and start["x"].shape[0] >= B
+        if from_start:
+            o.set_state(**{k: v[:B] for k, v in start["state"].items()})
+            x = start["x"][:B].copy()
+        else:
+            x = np.tile(X0, (B, 1))
         for _ in range(2):
             w, _ = o.step(x)
             x = o.plant_control_period(x, w, 0.01, 5e-3)[0]
@@ -142,7 +148,9 @@ def cpu_baseline(N, nb, seed, budget_s=18.0, refs=None):
         o.close()
     best = max(runs, key=lambda r: r["steps_per_s"])
     return {"value": best["steps_per_s"], "unit": "control steps/s", "cores": best["threads"], "kind": "port",
-            "sample": f"{best['quads']} quads x {best['steps']} closed-loop steps from hover, N={N} nb={nb}, fp64 C++ oracle "
+            "sample": f"{best['quads']} quads x {best['steps']} closed-loop steps "
+                      + ("continued from the end state of the GPU run (same flights, same regime)" if from_start else "from hover")
+                      + f", N={N} nb={nb}, fp64 C++ oracle "
                       f"(dense condensing + IPM, per-thread workspaces), OpenMP {best['threads']} threads, "
                       f"{'-march=native' if native else 'generic'} build",
             "single_thread_steps_per_s": runs[0]["steps_per_s"], "us_per_step_per_thread": best["us_per_step_per_thread"],
@@ -250,6 +258,9 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    start = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # where the CPU baseline continues from
+        start = {"state": e.get_state(), "x": e.sim_get_state()[0]}
     ktime, klaunch = e.get_kernel_time()     # HIP events around the step_kernel launches of the timed region (all of them when steps <= 50, else every 4th)
     kmin, kmax = e.get_kernel_time_minmax()
     its = e.get_qp_iter()
@@ -367,7 +378,7 @@ def main():
                                             "Both place 4 quadrotors per CU"}
             e2.close()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(N, nb, args.seed, refs=refs)
+            out["cpu_baseline"] = cpu_baseline(N, nb, args.seed, refs=refs, start=start)
         print(json.dumps(out))
     rccl_ok = world == 1 or stats_reduce == "rccl"
     if dist is not None:
