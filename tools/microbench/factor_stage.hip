@@ -1,0 +1,66 @@
+// Diagnostic (GPU box): time of one stage of the Riccati factorisation / of the sweeps in isolation -- 1 024 workgroups of
+// one wave (one per SIMD, as in the product at B = 1 024) run the phase REPS times on zeroed data (the instruction path does
+// not depend on the values).   build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-strict-aliasing [-DVARIANT...] -o fs factor_stage.hip
+#define MPCQ_UNROLL_FACTOR 2
+#define MPCQ_UNROLL_SWEEP 10
+#include "../../mpc_quad_ros_amd/csrc/mpcq_kernels.hpp"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+using namespace mpcq;
+typedef Cfg<double, true, 20, 10, false> C;
+
+template <int WHAT> __global__ __launch_bounds__(64) void kern(DevModel<double> m, double* stage, int reps, int* sink) {
+  const Lds L = lds_layout(20, 10, 1);
+  double* S = reinterpret_cast<double*>(smem_raw + L.dbytes);
+  double* G = stage + (size_t)blockIdx.x * L.gtotal;
+  int acc = 0;
+  for (int r = 0; r < reps; ++r) {
+    if (WHAT == 0) acc += riccati_factor<C, false>(m, S, G, L) ? 1 : 0;
+    if (WHAT == 1) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, L, &g, G + L.mrow, G + L.pst, -1) ? 1 : 0; }
+    if (WHAT == 2) riccati_forward<C>(m, S, G, L, L.dz);
+    if (WHAT == 3) riccati_backward_vec<C>(m, S, G, L, false);
+    if (WHAT == 4) riccati_forward<C, true>(m, S, G, L, L.dz);
+    if (WHAT == 5) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, L, &g, G + L.mrow, (double*)nullptr, -1) ? 1 : 0; }
+    if (WHAT == 6) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, L, &g, (double*)nullptr, (double*)nullptr, -1) ? 1 : 0; }
+    if (WHAT == 7) acc += riccati_factor<C, true>(m, S, G, L) ? 1 : 0;
+  }
+  if (acc == 12345) sink[blockIdx.x] = acc;
+}
+
+template <int WHAT> static void run(const char* name, DevModel<double> m, double* stage, int* sink, size_t lds, int B, int reps) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&kern<WHAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(kern<WHAT>, dim3(B), dim3(64), lds, 0, m, stage, 2, sink);
+  hipDeviceSynchronize();
+  hipEventRecord(a);
+  hipLaunchKernelGGL(kern<WHAT>, dim3(B), dim3(64), lds, 0, m, stage, reps, sink);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms = 0; hipEventElapsedTime(&ms, a, b);
+  hipError_t e = hipGetLastError();
+  printf("%-50s %8.3f us per call  = %7.0f ns per stage   (%s)\n", name, 1e3 * ms / reps, 1e6 * ms / reps / 20, hipGetErrorString(e));
+}
+
+int main() {
+  const int B = 1024, reps = 200;
+  const Lds L = lds_layout(20, 10, 1);
+  const size_t lds = lds_bytes<double>(L);
+  DevModel<double> m; memset(&m, 0, sizeof(m));
+  m.N = 20; m.nb = 10; m.B = B; m.gab = 1; m.eps = 1.1e-16;
+  double* stage; int* sink;
+  hipMalloc(&stage, (size_t)B * L.gtotal * sizeof(double)); hipMemset(stage, 0, (size_t)B * L.gtotal * sizeof(double));
+  hipMalloc(&sink, B * sizeof(int));
+  // NOTE: LDS is not initialised: the working-set masks are whatever the previous kernel left, so the "active set" rows time
+  // a mix of pinned and free inputs (the row stores of pinned inputs included); the instruction path of the interior-point
+  // factorisation and of the sweeps does not depend on the data.
+  printf("LDS per workgroup %zu bytes, global record %zu bytes\n", lds, (size_t)L.gtotal * sizeof(double));
+  run<0>("factor (interior point)", m, stage, sink, lds, B, reps);
+  run<1>("factor (active set, affine, store)", m, stage, sink, lds, B, reps);
+  run<5>("factor (active set, affine, no P store)", m, stage, sink, lds, B, reps);
+  run<6>("factor (active set, affine, no P store, no rows)", m, stage, sink, lds, B, reps);
+  run<7>("factor (active set masks only)", m, stage, sink, lds, B, reps);
+  run<2>("forward sweep", m, stage, sink, lds, B, reps);
+  run<3>("backward vector recursion", m, stage, sink, lds, B, reps);
+  run<4>("forward sweep (affine)", m, stage, sink, lds, B, reps);
+  return 0;
+}
