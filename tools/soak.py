@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): long closed-loop run of the bench workload in both precisions -- solver failures, tracking, and the
-bitwise agreement of the lockstep and the free-running launch modes.  usage: soak.py [periods] [seed]"""
+bitwise agreement of the lockstep and the free-running launch modes.  usage: [SOAK_B= SOAK_N= SOAK_NB=] soak.py [periods] [seed]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ import bench
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-B, N, nb = 1024, 20, 10
+B, N, nb = int(os.environ.get('SOAK_B', 1024)), int(os.environ.get('SOAK_N', 20)), int(os.environ.get('SOAK_NB', 10))
 refs = bench.workload(seed, 0, B, K + 10)
 for prec, name in ((0, "f64"), (1, "f32")):
     e1, _ = bench.make_engine(B, N, nb, prec, 0, 0, seed, periods=K + 10, refs=refs)
