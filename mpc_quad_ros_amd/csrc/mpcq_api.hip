@@ -280,10 +280,16 @@ struct EngineT : mpcq_engine {
     // lockstep: off 2.15 M steps/s, 8 -> 2.24, 4 -> 2.28, 2 -> 2.28)
     m.flip_max = 2;
     if (const char* t = getenv("MPCQ_FLIP_MAX")) m.flip_max = atoi(t);
-    // (bench workload, lockstep: never -> 2.37 M steps/s, 8 -> 2.44, 6 -> 2.48, 5 -> 2.47, 4 -> 2.45, 3 -> 2.44; a rule on the pins +
-    // releases accumulated over the passes added nothing)
-    m.abort_pins = N > 20 ? (3 * N) / 10 : 6;   // measured at N = 20; longer horizons in proportion
+    // Early exits of the warm attempt, measured on TWO workloads (lockstep M steps/s: bench missions | round-1 spline flights 150
+    // periods in, tools/round1_workload.py): a first pass that pins >= abort_pins inputs -- never 2.37 | 4.35, 10 -> 2.38 | 4.33,
+    // 8 -> 2.44 | 3.75, 6 -> 2.48 | 3.21; a multiplier check with >= abort_wrong wrong signs (with abort_pins 10) -- 10 -> 2.44 | 4.35,
+    // 8 -> 2.45 | 4.10, 7 -> 2.46 | 3.55, 5 -> 2.48 | 2.91.  The spline flights' saturated stretches shift along the horizon and the
+    // active-set passes follow them in 3-4 factorisations even after many pins; the missions' working sets move to other
+    // rotors.  Defaults: the most aggressive pair that costs the spline flights nothing.
+    m.abort_pins = N > 20 ? N / 2 : 10;
     if (const char* t = getenv("MPCQ_ABORT_PINS")) m.abort_pins = atoi(t);
+    m.abort_wrong = N > 20 ? (9 * N) / 20 : 9;
+    if (const char* t = getenv("MPCQ_ABORT_WRONG")) m.abort_wrong = atoi(t);
     m.pdas_max = 0;   // passes in which pins and releases may happen together (fp64 active-set method; measured on the bench workload: such passes are rare, 0.2 % of the quadrotor-steps, and the multiplier evaluations they need cost 4 % of the launch time)
     if (const char* t = getenv("MPCQ_PDAS")) m.pdas_max = atoi(t);
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;

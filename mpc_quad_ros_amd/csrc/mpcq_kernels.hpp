@@ -135,6 +135,7 @@ struct DevModel {
   int warm_retry; // cap of the warm attempt in the period after one that fell back to the interior point
   int flip_max;   // more changed bound states than this in a fallback solve: the next period skips the warm attempt (< 0: never)
   int abort_pins; // warm attempt given up after its first pass when that pins at least this many inputs (0: never)
+  int abort_wrong; // ... or when a multiplier check finds at least this many wrong signs (0: never)
   int pdas_max;   // passes in which wrong-signed multipliers are released even at an infeasible minimiser (0: primal rule only)
   int gab;   // stage records (AB'', c, qv) live in DevState::stage instead of LDS (must match the kernel instantiation)
   double h, dt_pred;
@@ -1656,10 +1657,13 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
         // followed by one re-pinning pass per stage.  Rule: per rotor only the worst multiplier goes (input i belongs to
         // rotor i & 3 = lane & 3: every lane sees one rotor); after bounces fewer rotors, in the end only the worst one overall.
         TQ vr = 0;
+        int nwrong = 0;
         for (int i = tid; i < nv; i += 64) {
           const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
-          if (a != TQ(0)) vr = tmax(vr, a < 0 ? -g : g);
+          if (a != TQ(0)) { const TQ v = a < 0 ? -g : g; vr = tmax(vr, v); nwrong += v > tolm ? 1 : 0; }
         }
+        // many wrong-signed multipliers at once in a warm attempt: the releases would go rotor by rotor, pass after pass
+        if (warm && m.abort_wrong > 0 && wave_sum(nwrong) >= m.abort_wrong) return false;
         TQ rel_thr = vmax;   // careful == 3: the worst one overall (the classical rule)
         if (careful < 3) {   // per rotor the worst one; after bounces only rotors whose worst is within 4x / 1.6x of the overall worst
           const TQ w0 = wave_max((tid & 3) == 0 ? vr : TQ(0)), w1 = wave_max((tid & 3) == 1 ? vr : TQ(0)),

@@ -56,7 +56,7 @@ def test_emu_saturating_references_many_working_sets():
 def test_emu_saturating_references_long_warm_attempts(monkeypatch):
     """The same references with the early exits of the warm active-set attempt switched off: many-pass attempts (pins and
     releases over several factorisations) end on the same optimum."""
-    monkeypatch.setenv("MPCQ_ABORT_PINS", "0"); monkeypatch.setenv("MPCQ_FLIP_MAX", "-1")
+    monkeypatch.setenv("MPCQ_ABORT_PINS", "0"); monkeypatch.setenv("MPCQ_ABORT_WRONG", "0"); monkeypatch.setenv("MPCQ_FLIP_MAX", "-1")
     monkeypatch.setenv("MPCQ_WARM_MAX", "14"); monkeypatch.setenv("MPCQ_WARM_RETRY", "14")
     worst, hist, failed = pc.case_saturating_references(make, B=2, K=14)
     print("saturating references, long warm attempts: worst", worst, "passes", dict(sorted(hist.items())))
