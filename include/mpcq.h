@@ -44,6 +44,8 @@ typedef enum mpcq_status {
 #define MPCQ_SOLVE_NAN 1          /* the QP step was not finite: the instance kept its previous iterate and control */
 #define MPCQ_SOLVE_MAXITER 2
 #define MPCQ_SOLVE_QP_FAILURE 4
+#define MPCQ_SOLVE_LOW_ACCURACY 8 /* MPCQ_PRECISION_F32 only: the step was taken, but its QP went through the interior-point fallback in
+                                     float -- outside the 1e-4 control budget (a warning, not a failure: mpcq_get_tracking_stats out[4] does not count it) */
 
 /* mpcq_config.flags.  MPCQ_FLAG_STATIC_GP: the GP in the model is a static one (use_gp = 1, gpe.type == "GP",
  * src/quad_opt.py:228-236 with src/gp/GP.py:136-175): basis = its training inputs, theta = (L, sigma_f,
@@ -51,8 +53,35 @@ typedef enum mpcq_status {
  * run the recursive update (mean and covariance stay as they are). */
 #define MPCQ_FLAG_STATIC_GP 1
 
+/* MPCQ_PRECISION_F64 (default): the reference's own arithmetic; <= 1e-7 relative control deviation from the fp64 oracle.
+ * MPCQ_PRECISION_F32: EXPERIMENTAL fast mode (model evaluation, sensitivities and QP solve in float; iterate, measurement
+ * and QP data differences stay double).  It meets the 1e-4 budget on solves that succeed from their warm start; a solve
+ * that went through the interior point ((qp_iter / 1000) % 10 != 0) is only good to ~1e-3 (worse on references that keep
+ * most inputs saturated) and is reported as such: status MPCQ_SOLVE_LOW_ACCURACY instead of 0. */
 #define MPCQ_PRECISION_F64 0
 #define MPCQ_PRECISION_F32 1
+
+/* Tuning of the box-QP solve (HPIPM's options in the reference's generated solver have no equivalent here: the
+ * algorithm differs, the optimum does not -- the QP is strictly convex).  Every field: 0 = the default for the
+ * precision; validated by mpcq_create (MPCQ_ERR_INVALID outside the stated range).  The defaults were measured on two
+ * workloads; results do not depend on them beyond rounding.  With MPCQ_TUNING=1 in the
+ * environment, MPCQ_WARM_MAX, MPCQ_WARM_RETRY, MPCQ_FLIP_MAX, MPCQ_ABORT_PINS, MPCQ_ABORT_WRONG, MPCQ_POLISH_MAX,
+ * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global, MPCQ_GENERIC=1 override
+ * the corresponding field (measurement scripts only; without MPCQ_TUNING=1 the environment is not consulted). */
+typedef struct mpcq_tuning {
+  int32_t warm_max;     /* passes of the warm active-set attempt, 1..64 (default 6 f64 / 12 f32) */
+  int32_t warm_retry;   /* ... in the period after a fallback solve, 1..64 (default 1) */
+  int32_t flip_max;     /* changed bound states in a fallback solve above which the next warm attempt is skipped, 1..512; -1: never (default 2) */
+  int32_t abort_pins;   /* warm attempt given up when its first pass pins this many inputs, 1..512; -1: never (default 10, N/2 for N > 20) */
+  int32_t abort_wrong;  /* ... or a multiplier check finds this many wrong signs, 1..512; -1: never (default 9, 9N/20 for N > 20) */
+  int32_t polish_max;   /* active-set passes behind the interior point, 1..64; -1: none, interior point to qp_tol (default 16 f64 / 12 f32) */
+  int32_t stage_mem;    /* placement of the per-stage records: 0 automatic, 1 LDS, 2 global memory (L2) */
+  int32_t generic_kernel; /* 1: the any-shape kernel instance even where a shape-specialised one exists */
+  double pin_ratio;     /* interior point -> working set: pinned where multiplier > pin_ratio x slack, (0, 1e3] (default 0.2 f64 / 1 f32) */
+  double ipm_mu0;       /* complementarity of the interior start in units of the gradient scale, [1e-12, 1] (default 1e-4) */
+  double ipm_margin;    /* interior start: distance from the bounds in units of their width, (0, 0.5) (default 0.1) */
+  double ipm_tol;       /* interior point -> active-set hand-over tolerance, [qp_tol, 1e-1] (default 1e-6 f64 / 1e-4 f32) */
+} mpcq_tuning;
 
 /* Engine configuration.  Replaces the constructor arguments of quad_optimizer
  * (quad, t_horizon, n_nodes, gpe; src/quad_opt.py:36) and the constants it bakes into the
@@ -77,6 +106,8 @@ typedef struct mpcq_config {
   int32_t qp_max_iter;   /* 0 = default */
   int32_t flags;         /* MPCQ_FLAG_* */
   double finish_radius;  /* EPSILON_TRAJECTORY_FINISHED [m], src/mpc_controller_node.py:118; 0 = default 1.0 */
+  /* ---- since 0.3 (callers built against an older header: mpcq_create_sized with THEIR sizeof(mpcq_config)) */
+  mpcq_tuning tune;      /* all-zero = defaults */
 } mpcq_config;
 
 typedef struct mpcq_engine mpcq_engine;
@@ -86,7 +117,11 @@ const char* mpcq_version(void);
 
 /* ---- lifetime.  quad_optimizer.__init__ (src/quad_opt.py:36-160): builds constants, K_x^-1,
  * allocates device state and zero-initialises the iterate (acados default), mu=0, C=K_x. */
-int mpcq_create(const mpcq_config* cfg, mpcq_engine** out);
+int mpcq_create(const mpcq_config* cfg, mpcq_engine** out);     /* cfg has THIS header's layout (== mpcq_create_sized(cfg, sizeof(mpcq_config), out)) */
+/* Versioned form: cfg_size = the caller's sizeof(mpcq_config).  Fields behind cfg_size take their defaults (0), so a
+ * caller built against an older header keeps working; sizes that end before `device` or exceed this library's struct
+ * are refused. */
+int mpcq_create_sized(const mpcq_config* cfg, uint64_t cfg_size, mpcq_engine** out);
 int mpcq_destroy(mpcq_engine* e);
 int mpcq_reset(mpcq_engine* e);
 
@@ -109,10 +144,18 @@ int mpcq_get_x(mpcq_engine* e, int32_t stage, double* out);      /* .get(stage,'
 int mpcq_get_u(mpcq_engine* e, int32_t stage, double* out);      /* .get(stage,'u') -> [B,4]  */
 int mpcq_get_cost(mpcq_engine* e, double* out);                  /* .get_cost()     -> [B]    */
 int mpcq_get_status(mpcq_engine* e, int32_t* out);               /* solve() status  -> [B]    */
-int mpcq_get_qp_iter(mpcq_engine* e, int32_t* out);              /* -> [B]: Riccati factorisations of the last solve (active-set passes +
-                                                                     interior-point iterations); + 1000 when the warm active-set attempt was given
-                                                                     up for the interior point; + 10000 when that solve also moved more than two
-                                                                     inputs on/off their bounds (the next solve then skips the warm attempt)   */
+/* -> [B]: decimal fields of the last solve.  qp_iter % 1000: Riccati factorisations (active-set passes + interior-point
+ * iterations); (qp_iter / 1000) % 10 != 0: the warm active-set attempt was given up or skipped, the solve went through
+ * the interior point ("fallback solve"); (qp_iter / 10000) % 10 != 0: that solve also moved more than flip_max inputs
+ * on/off their bounds (the next solve skips the warm attempt); qp_iter / 100000: why the warm attempt ended
+ * (MPCQ_WARM_*), 0 when it succeeded or there was none (cold start). */
+int mpcq_get_qp_iter(mpcq_engine* e, int32_t* out);
+#define MPCQ_WARM_BUDGET 1    /* pass budget (warm_max / warm_retry) exhausted */
+#define MPCQ_WARM_PINS 2      /* first pass pinned >= abort_pins inputs */
+#define MPCQ_WARM_WRONG 3     /* a multiplier check found >= abort_wrong wrong signs */
+#define MPCQ_WARM_BOUNCE 4    /* a bulk release bounced back with most inputs saturated */
+#define MPCQ_WARM_NUMERIC 5   /* a stage Hessian was not positive definite / not a number */
+#define MPCQ_WARM_SKIPPED 6   /* skipped: the previous solve carried the flip mark */
 /* .get_stats('time_tot'): device time of the last solve/step launch in seconds (whole batch) */
 int mpcq_get_stats(mpcq_engine* e, double* time_tot);
 

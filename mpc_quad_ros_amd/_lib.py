@@ -19,6 +19,7 @@ SYMBOLS = [
     ("mpcq_last_error", ctypes.c_char_p, []),
     ("mpcq_version", ctypes.c_char_p, []),
     ("mpcq_create", ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    ("mpcq_create_sized", ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.POINTER(_vp)]),
     ("mpcq_destroy", ctypes.c_int, [_vp]),
     ("mpcq_reset", ctypes.c_int, [_vp]),
     ("mpcq_set_trajectories", ctypes.c_int, [_vp, _dp, _ip, ctypes.c_int32]),

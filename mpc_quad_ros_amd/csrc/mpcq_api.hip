@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,7 +15,6 @@
 
 #include "../../include/mpcq.h"
 #include "mpcq_kernels.hpp"
-#include "mpcq_dense.hpp"
 
 namespace mpcq {   // mpcq_spec.hip, one translation unit per specialised shape
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
@@ -132,6 +132,7 @@ struct mpcq_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_time = 0;
   bool have_traj = false, timed = false;
+  bool tuning_env = false;   // MPCQ_TUNING=1: measurement scripts may override tuning fields through the environment
   void* comm = nullptr;
   int nranks = 1;
   double* d_stats5 = nullptr;
@@ -184,9 +185,6 @@ struct EngineT : mpcq_engine {
   double* h_pin = nullptr;   // pinned staging of the host-buffer step: [x_meas B*13 | w B*4 | x_pred B*13]
   double *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr, *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
   int* d_tlen = nullptr;
-  bool defer = false;        // two-phase lockstep period: interior-point solves in the dense kernel (mpcq_dense.hpp)
-  int parity = 0;            // which of the two deferral counters the next period uses
-  size_t dense_lds = 0;
   double* d_cmd = nullptr;   // [B*8] rotor thrusts, collective thrust, body rates (mpcq_get_command); also the chunk read-back
   size_t cmd_elems = 0;
   std::vector<T> hbuf;
@@ -194,7 +192,7 @@ struct EngineT : mpcq_engine {
 
   ~EngineT() override {
     DeviceGuard guard(cfg.device);
-    void* ptrs[] = {st.defer_rec, st.defer_list, st.defer_cnt, st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
+    void* ptrs[] = {st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
                     st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -249,49 +247,34 @@ struct EngineT : mpcq_engine {
     m.qp_max_iter = c.qp_max_iter > 0 ? c.qp_max_iter : 60;
     m.qp_tol = (T)(c.qp_tol > 0 ? c.qp_tol : (f32 ? 2e-6 : 1e-11));
     m.eps = f32 ? (T)6e-8 : (T)1.1e-16;
-    m.ipm_tol = f32 ? (T)1e-4 : (T)1e-6;
-    m.polish_max = f32 ? 12 : 16;   // fp64 passes alternate between a multiplier check and an affine solve: twice the count of fp32's
-    if (const char* t = getenv("MPCQ_IPM_TOL")) m.ipm_tol = (T)atof(t);
-    if (const char* t = getenv("MPCQ_POLISH_MAX")) m.polish_max = atoi(t);
-    // passes of the warm active-set attempt before falling back to the IPM (fp64: one factorisation each, an interior-point
-    // solve costs about 15 of them; measured on the min-snap bench workload, lockstep,
-    // with the interior point started at 0.1: 24 -> 1.14 M steps/s, 10 -> 1.21 M, 6 -> 1.31 M; started at 1e-4: 10/3 -> 1.56 M, 8/2 -> 1.67 M, 6/1 -> 1.80 M, 4/1 -> 1.82 M)
-    m.warm_max = f32 ? 12 : 6;
-    if (const char* t = getenv("MPCQ_WARM_MAX")) m.warm_max = atoi(t);
-    m.ipm_margin = (T)0.1;
-    if (const char* t = getenv("MPCQ_IPM_MARGIN")) m.ipm_margin = (T)atof(t);
-    // hand-over from the interior point: an input joins the working set when its multiplier exceeds pin_ratio x its slack.  Below 1
-    // the weakly active inputs (multiplier ~ slack ~ sqrt(mu)) are pinned at once instead of costing a pinning pass later; wrongly
-    // pinned ones are released by the multiplier check of the same pass (bench workload, lockstep: 10 -> 2.16 M steps/s,
-    // 1 -> 2.28, 0.3 -> 2.35, 0.2 -> 2.37, 0.1 -> 2.36, 0.05 -> 2.31, 0.01 -> 2.21)
-    // fp32 keeps 1: its multiplier sign test cannot tell a wrongly pinned weakly active input from a rightly pinned one, and the
-    // solve would end on a neighbouring vertex (worst control deviation on the tumbling reference log 1.2e-3 -> 4.1e-2)
-    m.pin_ratio = f32 ? (T)1 : (T)0.2;
-    if (const char* t = getenv("MPCQ_PIN_RATIO")) m.pin_ratio = (T)atof(t);
-    // complementarity of the interior start in units of the gradient scale.  The start is the previous solution pushed inside the
-    // box, i.e. close to the new optimum: a small value makes it a warm start (measured, bench workload, fp64 lockstep:
-    // 0.1 -> 1.36 M steps/s, 1e-2 -> 1.44, 1e-3 -> 1.54, 1e-4 -> 1.68, 1e-5 -> 1.61, 1e-6 -> 1.44)
-    m.ipm_mu0 = (T)1e-4;   // fp32 lockstep: 0.1 -> 1.63 M, 1e-4 -> 2.01 M
-    if (const char* t = getenv("MPCQ_IPM_MU0")) m.ipm_mu0 = (T)atof(t);
-    m.warm_retry = 1;
-    if (const char* t = getenv("MPCQ_WARM_RETRY")) m.warm_retry = atoi(t);
+    // ---- solver tuning: mpcq_config.tune (0 = default), validated by mpcq_create_sized; with MPCQ_TUNING=1 the environment
+    // overrides a field (measurement scripts).  How the defaults were measured: DESIGN.md section 3.3.
+    const mpcq_tuning& tu = c.tune;
+    const bool env = tuning_env = getenv("MPCQ_TUNING") && atoi(getenv("MPCQ_TUNING")) != 0;
+    auto ienv = [&](const char* name, int v) { const char* t = env ? getenv(name) : nullptr; return t ? atoi(t) : v; };
+    auto fenv = [&](const char* name, double v) { const char* t = env ? getenv(name) : nullptr; return t ? atof(t) : v; };
+    auto off = [](int v) { return v < 0 ? 0 : v; };   // -1 = "never": the kernel's encoding is 0 (flip_max: -1)
+    m.ipm_tol = (T)fenv("MPCQ_IPM_TOL", tu.ipm_tol > 0 ? tu.ipm_tol : (f32 ? 1e-4 : 1e-6));
+    // fp64 passes alternate between a multiplier check and an affine solve: twice the count of fp32's
+    m.polish_max = ienv("MPCQ_POLISH_MAX", tu.polish_max ? off(tu.polish_max) : (f32 ? 12 : 16));
+    // passes of the warm active-set attempt before falling back to the interior point (fp64: one factorisation each, an
+    // interior-point solve costs about 15 of them)
+    m.warm_max = ienv("MPCQ_WARM_MAX", tu.warm_max > 0 ? tu.warm_max : (f32 ? 12 : 6));
+    m.warm_retry = ienv("MPCQ_WARM_RETRY", tu.warm_retry > 0 ? tu.warm_retry : 1);
+    m.ipm_margin = (T)fenv("MPCQ_IPM_MARGIN", tu.ipm_margin > 0 ? tu.ipm_margin : 0.1);
+    // hand-over from the interior point: an input joins the working set when its multiplier exceeds pin_ratio x its slack.
+    // fp32 keeps 1: its multiplier sign test cannot tell a wrongly pinned weakly active input from a rightly pinned one
+    m.pin_ratio = (T)fenv("MPCQ_PIN_RATIO", tu.pin_ratio > 0 ? tu.pin_ratio : (f32 ? 1.0 : 0.2));
+    // complementarity of the interior start in units of the gradient scale: the start is the previous solution pushed inside
+    // the box, i.e. close to the new optimum, a small value makes it a warm start
+    m.ipm_mu0 = (T)fenv("MPCQ_IPM_MU0", tu.ipm_mu0 > 0 ? tu.ipm_mu0 : 1e-4);
     // a fallback solve whose solution changed more than this many bound states against the previous one marks a quadrotor whose
-    // saturated inputs flip between rotors every period: its next solve goes to the interior point directly (bench workload,
-    // lockstep: off 2.15 M steps/s, 8 -> 2.24, 4 -> 2.28, 2 -> 2.28)
-    m.flip_max = 2;
-    if (const char* t = getenv("MPCQ_FLIP_MAX")) m.flip_max = atoi(t);
-    // Early exits of the warm attempt, measured on TWO workloads (lockstep M steps/s: bench missions | round-1 spline flights 150
-    // periods in, tools/round1_workload.py): a first pass that pins >= abort_pins inputs -- never 2.37 | 4.35, 10 -> 2.38 | 4.33,
-    // 8 -> 2.44 | 3.75, 6 -> 2.48 | 3.21; a multiplier check with >= abort_wrong wrong signs (with abort_pins 10) -- 10 -> 2.44 | 4.35,
-    // 8 -> 2.45 | 4.10, 7 -> 2.46 | 3.55, 5 -> 2.48 | 2.91.  The spline flights' saturated stretches shift along the horizon and the
-    // active-set passes follow them in 3-4 factorisations even after many pins; the missions' working sets move to other
-    // rotors.  Defaults: the most aggressive pair that costs the spline flights nothing.
-    m.abort_pins = N > 20 ? N / 2 : 10;
-    if (const char* t = getenv("MPCQ_ABORT_PINS")) m.abort_pins = atoi(t);
-    m.abort_wrong = N > 20 ? (9 * N) / 20 : 9;
-    if (const char* t = getenv("MPCQ_ABORT_WRONG")) m.abort_wrong = atoi(t);
-    m.pdas_max = 0;   // passes in which pins and releases may happen together (fp64 active-set method; measured on the bench workload: such passes are rare, 0.2 % of the quadrotor-steps, and the multiplier evaluations they need cost 4 % of the launch time)
-    if (const char* t = getenv("MPCQ_PDAS")) m.pdas_max = atoi(t);
+    // saturated inputs flip between rotors every period: its next solve goes to the interior point directly
+    m.flip_max = ienv("MPCQ_FLIP_MAX", tu.flip_max ? tu.flip_max : 2);
+    // early exits of the warm attempt: a first pass that pins >= abort_pins inputs, a multiplier check with >= abort_wrong
+    // wrong signs (the most aggressive pair that costs the round-1 spline flights nothing)
+    m.abort_pins = ienv("MPCQ_ABORT_PINS", tu.abort_pins ? off(tu.abort_pins) : (N > 20 ? N / 2 : 10));
+    m.abort_wrong = ienv("MPCQ_ABORT_WRONG", tu.abort_wrong ? off(tu.abort_wrong) : (N > 20 ? (9 * N) / 20 : 9));
     if (m.ipm_tol < m.qp_tol) m.ipm_tol = m.qp_tol;
     m.h = c.T / c.N; m.dt_pred = c.dt_pred;
     m.finish_r = c.finish_radius > 0 ? c.finish_radius : 1.0;
@@ -361,7 +344,7 @@ struct EngineT : mpcq_engine {
 #endif
     st.tlen = d_tlen; st.traj = nullptr; st.x_meas = d_xin;
     // Placement of the per-stage records (AB'', c, qv): LDS when the whole batch is resident at once that way,
-    // otherwise global memory (L2 / MALL) if that lets more instances share a CU.  MPCQ_STAGE_MEM=lds|global overrides.
+    // otherwise global memory (L2 / MALL) if that lets more instances share a CU.  mpcq_config.tune.stage_mem overrides.
     int n_cu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
     const size_t lds_cu = 160 * 1024;
@@ -369,34 +352,21 @@ struct EngineT : mpcq_engine {
     const size_t bl = mpcq::lds_bytes<T>(Ll), bg = mpcq::lds_bytes<T>(Lg);
     const size_t occ_l = bl <= lds_cu ? lds_cu / bl : 0, occ_g = bg <= lds_cu ? lds_cu / bg : 0;
     bool gab = occ_l == 0 || (occ_g > occ_l && (size_t)B > occ_l * n_cu);
-    if (const char* t = getenv("MPCQ_STAGE_MEM")) gab = t[0] == 'g' || t[0] == 'G';
+    if (tu.stage_mem) gab = tu.stage_mem == 2;
+    if (const char* t = env ? getenv("MPCQ_STAGE_MEM") : nullptr) gab = t[0] == 'g' || t[0] == 'G';
     if (gab && occ_g == 0) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS (N/nb too large for this precision)");
-    if (!gab && occ_l == 0) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS with MPCQ_STAGE_MEM=lds");
+    if (!gab && occ_l == 0) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS with the stage records in LDS (tune.stage_mem = 1)");
     m.gab = gab ? 1 : 0;
-    if (getenv("MPCQ_VERBOSE")) fprintf(stderr, "mpcq: stage records in %s, LDS %zu B per instance (%zu per CU), lds-only layout %zu B (%zu per CU)\n", gab ? "global memory" : "LDS", gab ? bg : bl, gab ? occ_g : occ_l, bl, occ_l);
+    if (env && getenv("MPCQ_VERBOSE")) fprintf(stderr, "mpcq: stage records in %s, LDS %zu B per instance (%zu per CU), lds-only layout %zu B (%zu per CU)\n", gab ? "global memory" : "LDS", gab ? bg : bl, gab ? occ_g : occ_l, bl, occ_l);
     L = gab ? Lg : Ll;
     lds_bytes = gab ? bg : bl;
     if ((rc = dalloc(st.stage, Bz * L.gtotal))) return rc;   // stage records (global placement) + multiplier rows
     kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false>>;
     // shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
     krun = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false, 0, -1, true>>;
-    if (!getenv("MPCQ_GENERIC")) {
+    if (!ienv("MPCQ_GENERIC", tu.generic_kernel)) {
       if (auto k = spec_step(N, nb, gab, false, (T*)nullptr)) kstep = k;
       if (auto k = spec_step(N, nb, gab, true, (T*)nullptr)) krun = k;
-    }
-    // Two-phase period (fp64 engines with the stage records in global memory, horizons whose dense Hessian fits LDS): the
-    // interior-point solves of a period run in the dense kernel instead of inside the launch of the whole batch.
-    // OFF unless MPCQ_DEFER=1: measured on the bench workload the dense kernel takes 1.24 ms per period (one wave per CU,
-    // bound by LDS round trips in its triangular solves and tile loops) against ~0.5 ms for the same solves inside the
-    // step kernel; results are identical (tests/test_engine_edges.py::_two_phase_period).  DESIGN.md section 9.
-    defer = false;
-    if (const char* t = getenv("MPCQ_DEFER")) defer = atoi(t) != 0 && sizeof(T) == 8 && gab && N <= 20;
-    if (defer) {
-      dense_lds = mpcq::dense_lds_bytes(N);
-      if ((rc = dalloc(st.defer_rec, Bz * mpcq::defer_stride(N)))) return rc;
-      if ((rc = dalloc(st.defer_list, 2 * Bz))) return rc;
-      if ((rc = dalloc(st.defer_cnt, 2))) return rc;
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::dense_ipm_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dense_lds));
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -452,18 +422,7 @@ struct EngineT : mpcq_engine {
   int set_params(const double* mu) override { return nb ? h2q(st.mu, mu, (size_t)B * 3 * nb) : 0; }
 
   int base_mode() const { return (cfg.flags & MPCQ_FLAG_STATIC_GP) ? mpcq::MODE_STATIC_GP : 0; }
-  // One lockstep control period on the stream: the step kernel over the batch and, in the two-phase form, the dense
-  // interior-point kernel and the finishing launch over the quadrotors that deferred their solve (both return at once
-  // when the list of the period is empty).
-  void launch_period(const mpcq::DevState<T>& s, int mode) {
-    if (!defer) { hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode); return; }
-    const int pm = parity ? mpcq::MODE_PARITY : 0;
-    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode | mpcq::MODE_DEFER | pm);
-    const int nd = B < 256 ? B : 256;
-    hipLaunchKernelGGL(mpcq::dense_ipm_kernel<T>, dim3(nd), dim3(mpcq::DT), dense_lds, stream, m, s, parity);
-    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, (mode & ~mpcq::MODE_PLANT_FIRST) | mpcq::MODE_FINISH | pm);
-    parity ^= 1;
-  }
+  void launch_period(const mpcq::DevState<T>& s, int mode) { hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode); }
   int launch_step(int mode) {
     HIP_TRY(hipEventRecord(ev0, stream));
     launch_period(st, mode);
@@ -548,7 +507,7 @@ struct EngineT : mpcq_engine {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_step_device_async needs mpcq_set_trajectories first");
     mpcq::DevState<T> s2 = st;   // measurement and control are float64 in every precision (DevState::x_meas / w)
     s2.x_meas = d_x;
-    if (d_w) s2.w = d_w;
+    s2.w_ext = d_w;   // the engine's own control record st.w is written as well (mpcq_get_command, mpcq_sim_plant_period(w = NULL))
     HIP_TRY(hipEventRecord(ev0, stream));
     launch_period(s2, mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode());
     HIP_TRY(hipGetLastError());
@@ -564,14 +523,13 @@ struct EngineT : mpcq_engine {
     // HIP events around every `stride`-th step-kernel launch (an event pair costs a few microseconds of dispatch
     // overlap, so only a sample of the launches carries one; MPCQ_KEV_STRIDE=1 times every launch)
     int stride = K <= 50 ? 1 : 4;   // short runs: every launch
-    if (const char* t = getenv("MPCQ_KEV_STRIDE")) stride = atoi(t) > 0 ? atoi(t) : 1;
+    if (const char* t = tuning_env ? getenv("MPCQ_KEV_STRIDE") : nullptr) stride = atoi(t) > 0 ? atoi(t) : 1;
     const int nev = (K + stride - 1) / stride;
     while ((int)kev.size() < 2 * nev) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
     HIP_TRY(hipEventRecord(ev0, stream));
     // The plant update between two control periods rides at the head of the next step launch (MODE_PLANT_FIRST), where
     // it overlaps that launch's global loads; only the update after the last period needs the plant kernel.
-    // MPCQ_SIM_SPLIT=1 restores one plant kernel per period.
-    static const bool split = getenv("MPCQ_SIM_SPLIT") != nullptr;
+    const bool split = false;
     s2.run_x = d_xs; s2.run_steps = 1; s2.run_nsub = n_sub; s2.run_dt = sim_dt;
     for (int k = 0; k < K; ++k) {
       const bool timed_launch = k % stride == 0;
@@ -728,11 +686,19 @@ struct EngineT : mpcq_engine {
 extern "C" {
 
 const char* mpcq_last_error(void) { return g_err.c_str(); }
-const char* mpcq_version(void) { return "mpcq 0.2 (gfx950)"; }
+const char* mpcq_version(void) { return "mpcq 0.3 (gfx950)"; }
 
-int mpcq_create(const mpcq_config* c, mpcq_engine** out) {
-  if (!c || !out) return fail(MPCQ_ERR_INVALID, "null argument");
+int mpcq_create(const mpcq_config* c, mpcq_engine** out) { return mpcq_create_sized(c, sizeof(mpcq_config), out); }
+int mpcq_create_sized(const mpcq_config* c_in, uint64_t cfg_size, mpcq_engine** out) {
+  if (!c_in || !out) return fail(MPCQ_ERR_INVALID, "null argument");
   *out = nullptr;
+  // fields behind the caller's struct size take their defaults (0); everything up to and including `flags` is required
+  if (cfg_size < offsetof(mpcq_config, finish_radius) || cfg_size > sizeof(mpcq_config))
+    return fail(MPCQ_ERR_INVALID, "mpcq_config size not understood by this library (built against a different mpcq.h?)");
+  mpcq_config cc;
+  std::memset(&cc, 0, sizeof(cc));
+  std::memcpy(&cc, c_in, (size_t)cfg_size);
+  const mpcq_config* c = &cc;
   if (c->batch <= 0 || c->N < 2 || c->N > 128 || c->nb < 0 || c->nb > 128 || c->skip < 1 || !(c->T > 0) || !(c->dt_pred > 0))
     return fail(MPCQ_ERR_INVALID, "bad batch/N/nb/skip/T/dt_pred");
   if (c->nb > 0 && (!c->basis || !c->theta)) return fail(MPCQ_ERR_INVALID, "nb > 0 needs basis and theta");
@@ -741,7 +707,21 @@ int mpcq_create(const mpcq_config* c, mpcq_engine** out) {
     if (!(c->u_ub[i] > c->u_lb[i])) return fail(MPCQ_ERR_INVALID, "u_ub must exceed u_lb");
   for (int i = 13; i < 17; ++i)
     if (!(c->W[i] > 0)) return fail(MPCQ_ERR_INVALID, "input weights must be positive (strictly convex QP)");
-  if (c->finish_radius < 0) return fail(MPCQ_ERR_INVALID, "finish_radius must be >= 0 (0 = default 1 m)");
+  if (!(c->finish_radius >= 0)) return fail(MPCQ_ERR_INVALID, "finish_radius must be >= 0 (0 = default 1 m)");
+  if (!(c->qp_tol >= 0) || c->qp_tol > 1e-1) return fail(MPCQ_ERR_INVALID, "qp_tol out of range [0, 1e-1]");
+  if (c->qp_max_iter < 0 || c->qp_max_iter > 500) return fail(MPCQ_ERR_INVALID, "qp_max_iter out of range [0, 500]");
+  {
+    const mpcq_tuning& t = c->tune;
+    auto irange = [](int v, int lo, int hi, bool neg1) { return v == 0 || (neg1 && v == -1) || (v >= lo && v <= hi); };
+    auto frange = [](double v, double lo, double hi) { return v == 0 || (v >= lo && v <= hi); };   // NaN fails both
+    if (!irange(t.warm_max, 1, 64, false) || !irange(t.warm_retry, 1, 64, false) || !irange(t.flip_max, 1, 512, true) ||
+        !irange(t.abort_pins, 1, 512, true) || !irange(t.abort_wrong, 1, 512, true) || !irange(t.polish_max, 1, 64, true) ||
+        !irange(t.stage_mem, 1, 2, false) || !irange(t.generic_kernel, 1, 1, false))
+      return fail(MPCQ_ERR_INVALID, "mpcq_config.tune: integer field out of range (see mpcq.h)");
+    if (!frange(t.pin_ratio, 1e-300, 1e3) || !frange(t.ipm_mu0, 1e-12, 1.0) || !(t.ipm_margin == 0 || (t.ipm_margin > 0 && t.ipm_margin < 0.5)) ||
+        !frange(t.ipm_tol, 1e-300, 1e-1))
+      return fail(MPCQ_ERR_INVALID, "mpcq_config.tune: real field out of range (see mpcq.h)");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(MPCQ_ERR_DEVICE, "no HIP device: libmpcq has no CPU path (the CPU restatement lives in oracle/ for tests only)");

@@ -85,13 +85,9 @@ constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded 
 constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
 constexpr int SUBS = 4 * SUBW + 1;  // per-stage stride of the records (odd: lanes of different stages hit different banks)
 
-enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4, MODE_PLANT_FIRST = 8, MODE_STATIC_GP = 16, MODE_DEFER = 32, MODE_FINISH = 64, MODE_PARITY = 128 };
-// MODE_DEFER / MODE_FINISH / MODE_PARITY: two-phase lockstep period (mpcq_dense.hpp).  A quadrotor whose warm active-set attempt is given
-// up does not run its interior-point solve inside the launch of the whole batch (it would hold the launch for ~0.5 ms while every other
-// workgroup has finished): it leaves its QP data in DevState::defer_rec and its index in the list of the period (MODE_DEFER); the dense
-// interior-point kernel solves the listed QPs, and a MODE_FINISH launch of this kernel over the list takes the step from there
-// (active-set iterations from the interior point's working set, full step, post phase).  MODE_PARITY selects which of the two list
-// counters the period uses.
+enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4, MODE_PLANT_FIRST = 8, MODE_STATIC_GP = 16 };
+// why a warm active-set attempt ended without a solution (field x 100000 of qp_iter; 0: it was not given up / there was none)
+enum : int { QPX_BUDGET = 1, QPX_PINS = 2, QPX_WRONG = 3, QPX_BOUNCE = 4, QPX_NUMERIC = 5, QPX_SKIPPED = 6 };
 // MODE_STATIC_GP: the GP of the model is fixed (mpcq_config.flags & MPCQ_FLAG_STATIC_GP): the post phase skips the RGP update.
 // MODE_RUN: free-running closed loop, DevState::run_* periods per launch.  MODE_PLANT_FIRST: the launch starts by
 // advancing the plant state run_x with the previous launch's control (lockstep closed loop without a plant kernel
@@ -136,7 +132,6 @@ struct DevModel {
   int flip_max;   // more changed bound states than this in a fallback solve: the next period skips the warm attempt (< 0: never)
   int abort_pins; // warm attempt given up after its first pass when that pins at least this many inputs (0: never)
   int abort_wrong; // ... or when a multiplier check finds at least this many wrong signs (0: never)
-  int pdas_max;   // passes in which wrong-signed multipliers are released even at an infeasible minimiser (0: primal rule only)
   int gab;   // stage records (AB'', c, qv) live in DevState::stage instead of LDS (must match the kernel instantiation)
   double h, dt_pred;
   double mass, J[3], tmax, xf[4], yf[4], zl[4], g;
@@ -167,6 +162,7 @@ struct DevState {
   const double* traj;    // [B][Tmax][13]
   const double* x_meas;  // [B][13]
   double* w;        // [B][4]
+  double* w_ext;    // [B][4] caller's control buffer of mpcq_step_device_async (nullptr: none); st.w is written as well
   double* xpred;    // [B][13]
   double* cost;     // [B]
   double* stats;    // [B][4]
@@ -177,9 +173,6 @@ struct DevState {
   int* qp_iter;
   int* finished;    // [B] trajectory finished (src/mpc_controller_node.py:374), sticky until new trajectories / reset
   TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
-  double* defer_rec;   // [B][defer_stride(N)] QP data in / interior point out of the deferred solves (two-phase period)
-  int* defer_list;     // [2][B] indices of the quadrotors deferred in this period, per counter parity
-  int* defer_cnt;      // [2]
   double* run_x;    // [B][13] plant states of the free-running closed loop (MODE_RUN; aliases x_meas)
   int run_steps, run_nsub;   // control periods per launch, plant substeps per period
   double run_dt;    // plant substep
@@ -257,8 +250,6 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   L.qtotal = o;
   return L;
 }
-// deferred-solve record (doubles): r0 lb ub [nv each] | dx0 [16] | z sl su ll lu [nv each] | gm, iterations, status, pad [16]
-__host__ __device__ inline int defer_stride(int N) { return 8 * N * NU + 32; }
 template <typename TQ> __host__ __device__ inline size_t lds_bytes(const Lds& L) { return (size_t)L.dbytes + (size_t)L.qtotal * sizeof(TQ); }
 
 // ------------------------------------------------------------------ small helpers
@@ -303,14 +294,6 @@ template <int CTRL> __device__ inline float dpp(float v) { return __int_as_float
 template <int CTRL> __device__ inline double dpp(double v) {
   return __hiloint2double(dpp<CTRL>(__double2hiint(v)), dpp<CTRL>(__double2loint(v)));
 }
-// value held by lane ^ 32 (rows 0,1 <-> rows 2,3): one v_permlane32_swap per dword, no LDS, no SGPR round trip
-__device__ inline int xrow2(int v) {
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  const u2 r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-  return (int)((lane_id() & 32) ? r[0] : r[1]);
-}
-__device__ inline float xrow2(float v) { return __int_as_float(xrow2(__float_as_int(v))); }
-__device__ inline double xrow2(double v) { return __hiloint2double(xrow2(__double2hiint(v)), xrow2(__double2loint(v))); }
 // sum over the four 16-lane rows (lanes c, c+16, c+32, c+48), result on every lane: after v_permlane16_swap(v, v) the two
 // outputs hold rows (0,0,2,2) and (1,1,3,3), after v_permlane32_swap rows (0,1,0,1) and (2,3,2,3) -- their sum is the
 // butterfly step on every lane, no select (gfx950; no LDS, no SGPR round trip)
@@ -812,7 +795,6 @@ MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dx
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[zo + i];
   __syncthreads();
-#ifndef MPCQ_MFMA_SWEEPS
   {   // vector-ALU form (see riccati_forward)
     const Sel<TQ> sel(h);
     const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
@@ -846,42 +828,7 @@ MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dx
       for (int d = 0; d < PD; ++d) qc[d] = qc[d + 1];
     }
     __syncthreads();
-    return;
   }
-#endif
-  const bool vl = c == 14;
-  const Sel<TQ> sel(h);
-  const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
-  constexpr int PD = Depth<GAB>::PD;
-  TQ vA[4], qa[PD + 1][4], qz[PD + 1][4], qc[PD + 1][4];
-  vl_load(S + dxo, h, vA);
-#pragma unroll
-  for (int d = 0; d < PD; ++d) {
-    const int id = d < N ? d : N - 1;
-    rm.load(A, id, qa[d]);
-    vl_load(S + L.vin + id * VS, h, qz[d]);
-    vl_load(A + L.c + id * VS, h, qc[d]);
-  }
-#pragma unroll MPCQ_UNROLL_SWEEP
-  for (int i = 0; i < N; ++i) {
-    const int ip = i + PD < N ? i + PD : N - 1;
-    rm.load(A, ip, qa[PD]);
-    vl_load(S + L.vin + ip * VS, h, qz[PD]);
-    vl_load(A + L.c + ip * VS, h, qc[PD]);
-    TQ vB[4], acc[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      vB[s] = sel.A[s] * vA[s] + sel.U[s] * qz[0][s];
-      acc[s] = (with_c ? qc[0][s] : TQ(0)) + sel.P[s] * vA[s];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], vB[s]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) vA[s] = acc[s];
-    shift<TQ, PD>(qa); shift<TQ, PD>(qz); shift<TQ, PD>(qc);
-    if (vl) vl_store(S + dxo + (i + 1) * VS, h, vA);
-  }
-  __syncthreads();
 }
 
 // adjoint sweep: grad = d/dz of the QP objective at (dx(z), z)
@@ -890,7 +837,6 @@ MPCQ_COLD void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
   __syncthreads();
-#ifndef MPCQ_MFMA_SWEEPS
   {   // vector-ALU form (see riccati_forward)
     const KMaj<TQ> km(L, N, h, c);
     constexpr int PD = Depth<GAB>::PD;
@@ -920,46 +866,7 @@ MPCQ_COLD void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
       for (int d = 0; d < PD; ++d) qq[d] = qq[d + 1];
     }
     __syncthreads();
-    return;
   }
-#endif
-  const bool vl = c == 14;
-  const Sel<TQ> sel(h);
-  const KMaj<TQ> km(L, N, h, c);
-  constexpr int PD = Depth<GAB>::PD;
-  TQ qd[4], qe[4], pi[4], dxv[4], qvv[4], qa[PD + 1][4], qq[PD + 1][4];
-  vl_load(S + L.wq, h, qd);
-  vl_load(S + L.wq + VS, h, qe);
-  vl_load(S + L.dx + N * VS, h, dxv);
-  vl_load(A + L.qv + N * VS, h, qvv);
-#pragma unroll
-  for (int s = 0; s < 4; ++s) pi[s] = qe[s] * dxv[s] + qvv[s];
-#pragma unroll
-  for (int d = 0; d < PD; ++d) {
-    const int id = N - 1 - d > 0 ? N - 1 - d : 0;
-    km.load(A, id, qa[d]);
-    vl_load(A + L.qv + id * VS, h, qq[d]);
-  }
-#pragma unroll MPCQ_UNROLL_SWEEP
-  for (int i = N - 1; i >= 0; --i) {
-    const int ip = i - PD > 0 ? i - PD : 0;
-    km.load(A, ip, qa[PD]);
-    vl_load(A + L.qv + ip * VS, h, qq[PD]);
-    TQ gv[4], acc[4] = {0, 0, 0, 0};
-    vl_load(S + L.dx + i * VS, h, dxv);
-    vl_load(S + L.vin + i * VS, h, gv);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], pi[s]);
-    TQ g[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      g[s] = acc[s] + gv[s];
-      pi[s] = sel.A[s] * acc[s] + sel.P[s] * pi[s] + (qd[s] * dxv[s] + qq[0][s]);
-    }
-    shift<TQ, PD>(qa); shift<TQ, PD>(qq);
-    if (vl) vl_store(S + L.grad + i * VS, h, g);
-  }
-  __syncthreads();
 }
 
 // backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
@@ -968,7 +875,6 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
-#ifndef MPCQ_MFMA_SWEEPS
   {   // vector-ALU form (see riccati_forward)
     const KMaj<TQ> km(L, N, h, c);
     const int lj = lane < NU ? lane : 0;
@@ -1006,44 +912,7 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
       shift<TQ, PD>(qa);
     }
     __syncthreads();
-    return;
   }
-#endif
-  const Sel<TQ> sel(h);
-  const KMaj<TQ> km(L, N, h, c);
-  const int lj = lane < NU ? lane : 0;
-  constexpr int PD = Depth<GAB>::PD;
-  TQ pv[4] = {0, 0, 0, 0}, qa[PD + 1][4];
-#pragma unroll
-  for (int d = 0; d < PD; ++d) km.load(A, N - 1 - d > 0 ? N - 1 - d : 0, qa[d]);
-#pragma unroll MPCQ_UNROLL_SWEEP
-  for (int i = N - 1; i >= 0; --i) {
-    km.load(A, i - PD > 0 ? i - PD : 0, qa[PD]);
-    TQ rv[4], acc[4] = {0, 0, 0, 0};
-    vl_load(S + L.vin + i * VS, h, rv);
-    const TQ kk = S[L.K + i * KS + h * ABW + c];
-    const V4<TQ> li = *reinterpret_cast<const V4<TQ>*>(S + L.Linv + i * 16 + lj * 4);
-    const TQ rtj = S[L.rt + i * NU + lj];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], pv[s]);
-    // gt_j = rho_j + (B^T p)_j sits in slot 10+j of column 14; fetch the four of them as scalars
-    TQ g[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] = bc(acc[in_s<TQ>(j)] + rv[in_s<TQ>(j)], 16 * in_h<TQ>(j) + 14);
-    // p_i = A^T p_{i+1} + K^T gt  (one k=4 tile: A operand K[h][c], B operand gt_h in column 14; pinned rows of K are 0)
-    const TQ gh = h == 0 ? g[0] : (h == 1 ? g[1] : (h == 2 ? g[2] : g[3]));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc[s] = sel.A[s] * acc[s] + sel.P[s] * pv[s];
-    mfma(acc, kk, gh);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) pv[s] = acc[s];
-    shift<TQ, PD>(qa);
-    if (lane < NU) {
-      const TQ kvj = -(li.a * g[0] + li.b * g[1] + li.c * g[2] + li.d * g[3]);
-      S[L.vin + i * VS + lane] = (polish && rtj < TQ(0)) ? TQ(0) : kvj;
-    }
-  }
-  __syncthreads();
 }
 
 // forward sweep: Dx_0 = 0; dz_i = K_i Dx_i + k_i ; Dx_{i+1} = A Dx_i + B dz_i   (out: S[dzo], S[L.Dx])
@@ -1056,7 +925,6 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
 // it group-uniform again: the inputs go through four v_readlane, the state through the LDS vector that the sweep writes anyway.
 template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
-#ifndef MPCQ_MFMA_SWEEPS
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
   constexpr bool F64 = sizeof(TQ) == 8;
   const Sel<TQ> sel(h);
@@ -1110,74 +978,6 @@ MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& 
     shift<TQ, PD>(qa);
   }
   __syncthreads();
-#else
-  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
-  const bool vl = c == 14;
-  const Sel<TQ> sel(h);
-  const RMaj<TQ> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c), rk(L.zb, L.K, KS, NU, h, c);
-  constexpr int PD = Depth<GAB>::PD;
-  const int xo = affine ? L.dx : L.Dx;
-  TQ vA[4] = {0, 0, 0, 0}, qa[PD + 1][4], qc[PD + 1][4], kc[4], kn[4], kv[4], kvn[4];
-  if (affine) vl_load(S + L.dx, h, vA);
-  else if (lane < VS) S[L.Dx + lane] = 0;
-#pragma unroll
-  for (int d = 0; d < PD; ++d) {
-    rm.load(A, d < N ? d : N - 1, qa[d]);
-    if (affine) vl_load(S + L.Dx + (d < N ? d : N - 1) * VS, h, qc[d]);
-  }
-  rk.load(S, 0, kc);
-  vl_load(S + L.vin, h, kv);
-#pragma unroll MPCQ_UNROLL_SWEEP
-  for (int i = 0; i < N; ++i) {
-    const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1;
-    rm.load(A, ig, qa[PD]);
-    if (affine) vl_load(S + L.Dx + ig * VS, h, qc[PD]);
-    rk.load(S, ip, kn);
-    vl_load(S + L.vin + ip * VS, h, kvn);
-    PF_FINE(11);
-    TQ acc[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc[s] = sel.K[s] * kv[s];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, kc[s], vA[s]);     // dz = K Dx + k : slots 0..3 of column 14
-    PF_FINE(12);
-    TQ vB[4];
-#ifdef MPCQ_NO_XROW
-    if (false) {
-#else
-    if (sizeof(TQ) == 8) {
-#endif
-      // f64: dz_j sits in register 0 of lane (j, 14) and is needed in slot 10 + j = RI(s, h) of the same column:
-      // (h, s) = (2,2), (3,2), (0,3), (1,3), i.e. two rows away -> one cross-half swap, no broadcast through SGPRs
-      const TQ dz = acc[0], t = xrow2(dz);
-      if (vl) S[dzo + i * NU + h] = dz;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) { vB[s] = sel.A[s] * vA[s]; acc[s] = sel.P[s] * vA[s] + (affine ? qc[0][s] : TQ(0)); }
-      vB[2] = h >= 2 ? t : vB[2];
-      vB[3] = h < 2 ? t : vB[3];
-    } else {
-      TQ d[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = sizeof(TQ) == 4 ? bc(acc[j], 14) : bc(acc[0], 16 * j + 14);   // slot j = RI(s,h)
-      if (lane < NU) S[dzo + i * NU + lane] = lane == 0 ? d[0] : (lane == 1 ? d[1] : (lane == 2 ? d[2] : d[3]));
-#pragma unroll
-      for (int s = 0; s < 4; ++s) { vB[s] = sel.A[s] * vA[s]; acc[s] = sel.P[s] * vA[s] + (affine ? qc[0][s] : TQ(0)); }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (h == in_h<TQ>(j)) vB[in_s<TQ>(j)] = d[j];
-    }
-    PF_FINE(13);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) mfma(acc, qa[0][s], vB[s]);
-    PF_FINE(14);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { vA[s] = acc[s]; kc[s] = kn[s]; kv[s] = kvn[s]; }
-    shift<TQ, PD>(qa);
-    if (affine) shift<TQ, PD>(qc);
-    if (vl) vl_store(S + xo + (i + 1) * VS, h, vA);
-  }
-  __syncthreads();
-#endif
 }
 
 // ------------------------------------------------------------------ QP: Riccati factorisation
@@ -1517,7 +1317,8 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const T
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
+  why = QPX_BUDGET;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
     for (int i = tid; i < nv; i += 64) {
@@ -1594,7 +1395,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
       const bool fok = riccati_factor<C, true, true>(m, S, A, L PF_PASS, &gfac, nact > 0 ? G + L.mrow : nullptr, keep_p ? G + L.pst : nullptr, top);
       top = -1;
       PF_STOP(PF_FACTOR);
-      if (!fok) return false;
+      if (!fok) { why = QPX_NUMERIC; return false; }
       gm = tmax(gm, tmax(TQ(1), gfac));   // a restarted factorisation sees only the stages it visits
       tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
       PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
@@ -1613,18 +1414,15 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
       if (zn < S[L.lb + i] || zn > S[L.ub + i]) flags |= 1;
     }
     flags = wave_reduce(flags, [](int a, int b) { return a | b; });
-    if (flags & 2) return false;
+    if (flags & 2) { why = QPX_NUMERIC; return false; }
     const bool feasible = !(flags & 1);
     // Multipliers of the pinned inputs at the minimiser of the working set, without a gradient sweep: with the
     // cost-to-go of the factorisation, lambda_a = gt_a + M_a dx_i + sum_{q free} (B'PB)_aq z_q + R_aa z_a (rows left
     // behind by riccati_factor).  A feasible minimiser with correctly signed multipliers is the solution.  Otherwise the
-    // wrong-signed ones are released -- at a feasible minimiser always (the classical primal rule); in the first
-    // `pdas_max` passes, while no release has bounced yet, also when the minimiser violates other bounds (primal-dual
-    // active-set rule: pins and releases in the same pass), which saves one factorisation per release in the cascades
-    // that make the slowest quadrotor of a launch.
+    // wrong-signed ones are released (only at a feasible minimiser: the classical primal rule).
     bool any_release = false;
     unsigned relnow = 0;
-    if (nact > 0 && (feasible || (passes < m.pdas_max && careful == 0))) {
+    if (nact > 0 && feasible) {
       TQ vmax = 0;
       for (int i = tid; i < nv; i += 64) {
         const TQ a = S[L.act + i];
@@ -1646,7 +1444,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
         S[L.grad + GI(i)] = lam;
       }
       vmax = wave_max(vmax);
-      if (!(vmax == vmax)) return false;
+      if (!(vmax == vmax)) { why = QPX_NUMERIC; return false; }
 #ifdef MPCQ_EMU_DEBUG
       if (tid == 0) printf("  polish pass %d warm %d feasible %d vmax %.3e tolm %.3e nact %d\n", passes, (int)warm, (int)feasible, (double)vmax, (double)tolm, nact);
 #endif
@@ -1663,7 +1461,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
           if (a != TQ(0)) { const TQ v = a < 0 ? -g : g; vr = tmax(vr, v); nwrong += v > tolm ? 1 : 0; }
         }
         // many wrong-signed multipliers at once in a warm attempt: the releases would go rotor by rotor, pass after pass
-        if (warm && m.abort_wrong > 0 && wave_sum(nwrong) >= m.abort_wrong) return false;
+        if (warm && m.abort_wrong > 0 && wave_sum(nwrong) >= m.abort_wrong) { why = QPX_WRONG; return false; }
         TQ rel_thr = vmax;   // careful == 3: the worst one overall (the classical rule)
         if (careful < 3) {   // per rotor the worst one; after bounces only rotors whose worst is within 4x / 1.6x of the overall worst
           const TQ w0 = wave_max((tid & 3) == 0 ? vr : TQ(0)), w1 = wave_max((tid & 3) == 1 ? vr : TQ(0)),
@@ -1720,10 +1518,10 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
     if (feasible && !any_release) { settled = true; passes += 1; break; }
     // a bulk release that bounces back wholesale with most of the inputs saturated: far from the optimal working set,
     // the interior point gets there faster
-    if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) return false;
+    if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) { why = QPX_BOUNCE; return false; }
     // the first minimiser of a warm attempt leaves the box in many inputs at once: the previous working set is no guess (the
     // saturated inputs moved to other rotors); passes would follow one another, the interior point gets there faster
-    if (warm && passes == 0 && m.abort_pins > 0 && nblk >= m.abort_pins) return false;
+    if (warm && passes == 0 && m.abort_pins > 0 && nblk >= m.abort_pins) { why = QPX_PINS; return false; }
     if (bounce && careful < 3) careful += 1;   // an input released in the previous pass is pinned again
     released = any_release;
     relmask = relnow;
@@ -1739,7 +1537,8 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
 // rollout and a gradient sweep first): used for TQ = float, where increments keep their accuracy while a from-scratch
 // affine solve would have to be refined again every time.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes PF_ARG) {
+MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
+  why = QPX_BUDGET;
   bool fresh = false;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
@@ -1779,7 +1578,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
       TQ gfac = 0;
       const bool fok = riccati_factor<C, true, true>(m, S, A, L PF_PASS, &gfac);
       PF_STOP(PF_FACTOR);
-      if (!fok) return false;
+      if (!fok) { why = QPX_NUMERIC; return false; }
       gm = tmax(TQ(1), gfac);
       tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
       tols = (sizeof(TQ) == 4 ? TQ(MPCQ_F32_TOLS) : TQ(64)) * m.eps * gm;
@@ -1823,7 +1622,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
     gF = wave_max(gF);
     vmax = wave_max(vmax);
     nact = wave_sum(na);
-    if (!(gF == gF)) return false;
+    if (!(gF == gF)) { why = QPX_NUMERIC; return false; }
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) { int na = 0; for (int i = 0; i < nv; ++i) na += S[L.act + i] != TQ(0); printf("  polish pass %d warm %d full %d gF %.3e vmax %.3e tolm %.3e tols %.3e nact %d\n", passes, (int)warm, (int)full, (double)gF, (double)vmax, (double)tolm, (double)tols, na); }
 #endif
@@ -1850,7 +1649,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, L PF_PASS); PF_STOP(PF_FACTOR); if (!fok) return false; }
+    if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, L PF_PASS); PF_STOP(PF_FACTOR); if (!fok) { why = QPX_NUMERIC; return false; } }
     else { riccati_backward_vec<C>(m, S, A, L, true); PF_STOP(PF_BWD); }
     refactor = false;
     PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
@@ -1881,7 +1680,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
     if (tid == 0) printf("     alpha %.6e nblk %d\n", (double)alpha, nblk);
 #endif
     full = nblk == 0;
-    if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) return false;   // wholesale bounce in a saturated regime: leave it to the interior point
+    if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) { why = QPX_BOUNCE; return false; }   // wholesale bounce in a saturated regime: leave it to the interior point
     if (nblk > 0) { refactor = true; if (released && careful < 3) careful += 1; }
     released = false;
     __syncthreads();
@@ -1901,55 +1700,32 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const int prev_iter, const int phase_in, double* rec PF_ARG) {
-  const int phase = C::RUN ? 0 : phase_in;   // the free-running instances have no two-phase period
+MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const int prev_iter PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
-  int it = 0, passes = 0, wpasses = 0;
+  int it = 0, passes = 0, wpasses = 0, why = 0;
   TQ gm = 1;
-  // prev_iter: pass count of this quadrotor's previous solve (0: cold start, >= 1000: its warm attempt was given up).  A
-  // quadrotor whose references are out of reach (inputs saturated over most of the horizon, the working set changing by
+  // prev_iter: this quadrotor's previous return value (0: cold start).  Decimal fields (qp_iter of include/mpcq.h):
+  //   passes + interior-point iterations | x 1000: the warm attempt was given up or skipped (fallback solve) |
+  //   x 10000: flip mark | x 100000: why the warm attempt ended (QPX_*).
+  // A quadrotor whose references are out of reach (inputs saturated over most of the horizon, the working set changing by
   // many inputs every period) fails the warm attempt period after period: after a fallback the next attempt is short
   // (warm_retry passes), so that such a quadrotor costs its launch one interior-point solve, not that plus a long
   // active-set attempt; the first period in which the short attempt succeeds restores the full budget.
-  // phase: 0 = everything inside this launch; MODE_DEFER = give the interior-point solve away (returns -1);
-  //        MODE_FINISH = the interior point comes from the dense kernel (rec), continue behind it
-  // prev_iter >= 10000: the previous solve fell back AND its solution differed from the one before in more than flip_max
+  // Flip mark: the previous solve fell back AND its solution differed from the one before in more than flip_max
   // bound states -- a quadrotor whose saturated inputs flip between rotors from period to period (infeasible references,
   // near-degenerate QPs): the previous working set is no guess at all there, the warm attempt is skipped altogether.
-  const bool flipping = m.flip_max >= 0 && prev_iter >= 10000;
-  const int warm_cap = flipping ? 0 : (prev_iter % 10000 >= 1000 ? m.warm_retry : m.warm_max);
-  if (flipping) wpasses = 1000;   // counts as a fallback solve
-  if (phase != MODE_FINISH && prev_iter > 0 && warm_cap > 0) {
-    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap PF_PASS)
-                        : polish_incremental<C>(m, S, A, L, gm, wpasses, true, warm_cap PF_PASS)) {   // sets z = 0 and its own gradient scale
+  const bool flipping = m.flip_max >= 0 && (prev_iter / 10000) % 10 != 0;
+  const int warm_cap = flipping ? 0 : ((prev_iter / 1000) % 10 != 0 ? m.warm_retry : m.warm_max);
+  if (flipping) { wpasses = 1000; why = QPX_SKIPPED; }   // counts as a fallback solve
+  if (prev_iter > 0 && warm_cap > 0) {
+    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap, why PF_PASS)
+                        : polish_incremental<C>(m, S, A, L, gm, wpasses, true, warm_cap, why PF_PASS)) {   // sets z = 0 and its own gradient scale
       *status = 0;
       return wpasses;
     }
     wpasses += 1000;
   }
   int st = 0;
-  if (!C::RUN && phase == MODE_DEFER) {
-    for (int i = tid; i < nv; i += 64) { rec[i] = (double)S[L.r0 + i]; rec[nv + i] = (double)S[L.lb + i]; rec[2 * nv + i] = (double)S[L.ub + i]; }
-    if (tid < VS) rec[3 * nv + tid] = (double)S[L.dx + tid];
-    if (tid == 0) rec[3 * nv + 16 + 5 * nv + 3] = (double)wpasses;
-    return -1;
-  }
-  bool from_dense = false;
-  if (!C::RUN && phase == MODE_FINISH) {
-    const double* o = rec + 3 * nv + 16;
-    from_dense = o[5 * nv + 2] == 0.0;      // the dense interior point converged
-    wpasses = (int)o[5 * nv + 3];   // 1000 + passes of the warm attempt the main launch gave up (0 after a cold start)
-    if (from_dense) {
-      for (int i = tid; i < nv; i += 64) {
-        S[L.z + i] = (TQ)o[i]; S[L.sl + i] = (TQ)o[nv + i]; S[L.su + i] = (TQ)o[2 * nv + i];
-        S[L.ll + i] = (TQ)o[3 * nv + i]; S[L.lu + i] = (TQ)o[4 * nv + i];
-      }
-      gm = (TQ)o[5 * nv];
-      it = (int)o[5 * nv + 1];
-      __syncthreads();
-    }
-  }
-  if (!from_dense) {
   // interior start
   for (int i = tid; i < nv; i += 64) {
     const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
@@ -1965,13 +1741,13 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = m.ipm_mu0 * gm / S[L.sl + i]; S[L.lu + i] = m.ipm_mu0 * gm / S[L.su + i]; }
   __syncthreads();
   st = ipm_run<C>(m, S, A, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
-  }
   bool need_roll = true;
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
-    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, passes, false, m.polish_max PF_PASS)
-                        : polish_incremental<C>(m, S, A, L, gm, passes, false, m.polish_max PF_PASS)) need_roll = false;
+    int why2 = 0;
+    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, passes, false, m.polish_max, why2 PF_PASS)
+                        : polish_incremental<C>(m, S, A, L, gm, passes, false, m.polish_max, why2 PF_PASS)) need_roll = false;
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
@@ -1992,7 +1768,7 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
     }
     chg = wave_sum(chg);
   }
-  return it + passes + wpasses + (m.flip_max >= 0 && chg > m.flip_max ? 10000 : 0);
+  return it + passes + wpasses + (m.flip_max >= 0 && chg > m.flip_max ? 10000 : 0) + 100000 * why;
 }
 
 // ------------------------------------------------------------------ RGP regress (3 axes, one new point each)
@@ -2068,16 +1844,7 @@ template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
   const int tid = lane_id();
   const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
-  // two-phase period (not in the free-running instances): which quadrotor this workgroup works on
-  const int phase = C::RUN ? 0 : (mode & (MODE_DEFER | MODE_FINISH));
-  const int par = (mode & MODE_PARITY) ? 1 : 0;
-  int b = blockIdx.x;
-  if (!C::RUN && phase == MODE_FINISH) {
-    if ((int)blockIdx.x >= st.defer_cnt[par]) return;
-    b = st.defer_list[par * m.B + blockIdx.x];
-  } else if (!C::RUN && phase == MODE_DEFER && blockIdx.x == 0 && tid == 0) {
-    st.defer_cnt[par ^ 1] = 0;   // the other period's counter: nobody touches it during this one
-  }
+  const int b = blockIdx.x;
   const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
   double* D = reinterpret_cast<double*>(smem_raw);
   TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
@@ -2195,15 +1962,13 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   }
   __syncthreads();
   PF_STOP(PF_LOAD);
-  // ---- 1. shooting (a MODE_FINISH launch finds the stage records of this period in the global record)
-  if (phase != MODE_FINISH) {
-    shoot_states<C>(m, D, S, A, L, gp);
-    __syncthreads();
-    PF_STOP(PF_SHOOT_X);
-    shoot_sens<C>(m, S, A, L);
-    __syncthreads();
-    PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
-  }
+  // ---- 1. shooting
+  shoot_states<C>(m, D, S, A, L, gp);
+  __syncthreads();
+  PF_STOP(PF_SHOOT_X);
+  shoot_sens<C>(m, S, A, L);
+  __syncthreads();
+  PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
   if (tid < VS) { S[L.dx + tid] = 0; A[L.AB + N * ABS + tid] = 0; S[L.zb + tid] = 0; }
   for (int it = tid; it < N * VS; it += 64) S[L.vin + it] = 0;
   __syncthreads();
@@ -2211,12 +1976,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  double* rec = (!C::RUN && phase) ? st.defer_rec + (size_t)b * defer_stride(N) : nullptr;
-  const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b], phase, rec PF_PASS);
-  if (!C::RUN && iters < 0) {   // deferred: nothing of this period has been written yet; the finish launch does the rest
-    if (tid == 0) st.defer_list[par * m.B + atomicAdd(&st.defer_cnt[par], 1)] = b;
-    return;
-  }
+  const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b] PF_PASS);
   PF_START();
   // ---- 3. full step (iterate accumulated in double).  A step that is not finite (a QP that broke down: only seen
   //      with the fp32 QP on infeasible references) is not taken: the iterate and the control of the previous period
@@ -2269,8 +2029,14 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   cst = wave_sum(cst);
   bad = wave_max(bad);
   if (bad) status = 1;
+  // TQ = float: a step whose QP went through the interior-point fallback is outside the 1e-4 control budget of the fast mode
+  // (include/mpcq.h, MPCQ_SOLVE_LOW_ACCURACY): taken, but reported
+  if (sizeof(TQ) == 4 && status == 0 && (iters / 1000) % 10 != 0) status = 8;
   if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; }
-  if (tid < NU) st.w[(size_t)b * NU + tid] = D[L.U + tid];
+  if (tid < NU) {
+    st.w[(size_t)b * NU + tid] = D[L.U + tid];
+    if (st.w_ext) st.w_ext[(size_t)b * NU + tid] = D[L.U + tid];
+  }
   PF_STOP(PF_ELEM);
   PF_START();
   if (mode & MODE_POST) {
@@ -2420,7 +2186,7 @@ static __global__ void stats_kernel(const double* stats, const int* status, int 
     a0 += stats[(size_t)b * 4]; a1 += stats[(size_t)b * 4 + 1]; a2 += stats[(size_t)b * 4 + 2];
     const double mx = stats[(size_t)b * 4 + 3];
     a3 = a3 > mx ? a3 : mx;
-    a4 += status[b] != 0 ? 1.0 : 0.0;
+    a4 += (status[b] & 7) != 0 ? 1.0 : 0.0;   // MPCQ_SOLVE_LOW_ACCURACY (8) is a warning, not a failed solve
   }
   sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = a2; sh[3][threadIdx.x] = a3; sh[4][threadIdx.x] = a4;
   __syncthreads();

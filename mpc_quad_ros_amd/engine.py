@@ -10,13 +10,38 @@ from . import _lib
 from .params import NU, NX, NY, EngineConfig
 
 
+# decimal fields of mpcq_get_qp_iter (include/mpcq.h)
+def qp_passes(it):
+    """Riccati factorisations of the solve (active-set passes + interior-point iterations)."""
+    return np.asarray(it) % 1000
+
+
+def qp_fallback(it):
+    """True where the warm active-set attempt was given up or skipped and the solve went through the interior point."""
+    return (np.asarray(it) // 1000) % 10 != 0
+
+
+def qp_flip(it):
+    """True where the solve carries the flip mark (the next one skips the warm attempt)."""
+    return (np.asarray(it) // 10000) % 10 != 0
+
+
+def qp_warm_exit(it):
+    """MPCQ_WARM_* code: why the warm attempt ended without a solution (0: it succeeded / there was none)."""
+    return np.asarray(it) // 100000
+
+
+WARM_BUDGET, WARM_PINS, WARM_WRONG, WARM_BOUNCE, WARM_NUMERIC, WARM_SKIPPED = 1, 2, 3, 4, 5, 6
+SOLVE_LOW_ACCURACY = 8
+
+
 class Engine:
     def __init__(self, cfg: EngineConfig, lib_path: str | None = None):
         self.cfg = cfg
         self.lib = _lib.load(lib_path)
         self._c = cfg.to_c()
         h = ctypes.c_void_p()
-        self._check(self.lib.mpcq_create(ctypes.byref(self._c), ctypes.byref(h)))
+        self._check(self.lib.mpcq_create_sized(ctypes.byref(self._c), ctypes.sizeof(self._c), ctypes.byref(h)))
         self.h = h
         self.B, self.N, self.nb = cfg.batch, cfg.N, cfg.nb
 

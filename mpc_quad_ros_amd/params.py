@@ -66,6 +66,19 @@ def default_W() -> np.ndarray:
     return np.concatenate((q_diag, np.full(4, 0.1)))
 
 
+class CTuning(ctypes.Structure):
+    """Binary layout of ``mpcq_tuning`` (include/mpcq.h); every field 0 = default."""
+    _fields_ = [
+        ("warm_max", ctypes.c_int32), ("warm_retry", ctypes.c_int32), ("flip_max", ctypes.c_int32),
+        ("abort_pins", ctypes.c_int32), ("abort_wrong", ctypes.c_int32), ("polish_max", ctypes.c_int32),
+        ("stage_mem", ctypes.c_int32), ("generic_kernel", ctypes.c_int32),
+        ("pin_ratio", ctypes.c_double), ("ipm_mu0", ctypes.c_double), ("ipm_margin", ctypes.c_double), ("ipm_tol", ctypes.c_double),
+    ]
+
+
+STAGE_MEM = {"auto": 0, "lds": 1, "global": 2}
+
+
 class CConfig(ctypes.Structure):
     """Binary layout of ``mpcq_config`` (include/mpcq.h); the oracle's ``orc_config`` has the
     same leading fields (it ignores device / precision / qp options)."""
@@ -84,6 +97,7 @@ class CConfig(ctypes.Structure):
         ("device", ctypes.c_int32), ("precision", ctypes.c_int32),
         ("qp_max_iter", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("finish_radius", ctypes.c_double),
+        ("tune", CTuning),
     ]
 
 
@@ -114,6 +128,7 @@ class EngineConfig:
     qp_max_iter: int = 0              # 0 -> implementation default
     static_gp: bool = False           # MPCQ_FLAG_STATIC_GP: fixed GP in the model (use_gp = 1), no recursive update in the step
     finish_radius: float = 0.0        # EPSILON_TRAJECTORY_FINISHED [m]; 0 -> 1.0 (src/mpc_controller_node.py:118)
+    tune: Optional[dict] = None       # mpcq_tuning fields by name (include/mpcq.h); stage_mem also as "lds" / "global"
 
     def __post_init__(self):
         if self.skip is None:
@@ -156,6 +171,12 @@ class EngineConfig:
         c.theta = self._theta_buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         c.device, c.precision, c.qp_max_iter, c.flags = self.device, self.precision, self.qp_max_iter, (1 if self.static_gp else 0)
         c.finish_radius = float(self.finish_radius)
+        for k, v in (self.tune or {}).items():
+            if k not in dict(CTuning._fields_):
+                raise ValueError(f"unknown tuning field {k!r}")
+            if k == "stage_mem" and isinstance(v, str):
+                v = STAGE_MEM[v]
+            setattr(c.tune, k, v)
         return c
 
 

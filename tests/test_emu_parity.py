@@ -2,6 +2,7 @@
 (tests/wave_emu: the unchanged mpc_quad_ros_amd/csrc files compiled for the host, one fiber per
 lane).  It checks lane logic / LDS layout / barriers of the kernels against the oracle where no
 GPU exists; the real parity gate is tests/test_gpu_parity.py on the MI355X."""
+import dataclasses
 import os
 import subprocess
 
@@ -50,18 +51,20 @@ def test_emu_saturating_references_many_working_sets():
     assert failed == 0
     print("saturating references: worst", worst, "passes", dict(sorted(hist.items())))
     assert worst < 1e-7
-    assert any(1000 <= v < 10000 for v in hist) and any(v >= 10000 for v in hist)   # fallbacks AND the direct interior-point solves of flipping quadrotors
+    from mpc_quad_ros_amd.engine import WARM_SKIPPED, qp_fallback, qp_flip, qp_warm_exit
+    assert any(qp_fallback(v) and not qp_flip(v) for v in hist) and any(qp_flip(v) for v in hist)
+    assert any(qp_warm_exit(v) == WARM_SKIPPED for v in hist)   # fallbacks AND the direct interior-point solves of flipping quadrotors
 
 
-def test_emu_saturating_references_long_warm_attempts(monkeypatch):
+def test_emu_saturating_references_long_warm_attempts():
     """The same references with the early exits of the warm active-set attempt switched off: many-pass attempts (pins and
     releases over several factorisations) end on the same optimum."""
-    monkeypatch.setenv("MPCQ_ABORT_PINS", "0"); monkeypatch.setenv("MPCQ_ABORT_WRONG", "0"); monkeypatch.setenv("MPCQ_FLIP_MAX", "-1")
-    monkeypatch.setenv("MPCQ_WARM_MAX", "14"); monkeypatch.setenv("MPCQ_WARM_RETRY", "14")
-    worst, hist, failed = pc.case_saturating_references(make, B=2, K=14)
+    tune = dict(abort_pins=-1, abort_wrong=-1, flip_max=-1, warm_max=14, warm_retry=14)
+    make_t = lambda cfg: make(dataclasses.replace(cfg, tune=tune))
+    worst, hist, failed = pc.case_saturating_references(make_t, B=2, K=14)
     print("saturating references, long warm attempts: worst", worst, "passes", dict(sorted(hist.items())))
     assert failed == 0 and worst < 1e-7
-    assert sum(n for v, n in hist.items() if 3 <= v <= 14) >= 4
+    assert sum(n for v, n in hist.items() if 3 <= v % 1000 <= 14 and v < 1000) >= 4
 
 
 def test_emu_lane_order_independent(monkeypatch):

@@ -316,34 +316,9 @@ def _static_gp_model_path(lib):
     assert not np.array_equal(e2.get_rgp()[0].reshape(B, -1), mu)
 
 
-def _two_phase_period(lib):
-    """MPCQ_DEFER=1: the interior-point solves of a lockstep period leave the step kernel (deferred to the dense
-    condensed-QP kernel, then finished by a second launch over the deferred quadrotors).  Same results as the
-    single-launch period: controls, iterate, RGP posterior, cursors and statistics on references that force fallbacks."""
-    import subprocess, sys, json
-    code = """
-import sys, json, numpy as np
-sys.path[:0] = [%r, %r]
-import parity_cases as pc
-from mpc_quad_ros_amd.engine import Engine
-make = lambda cfg: Engine(cfg, lib_path=%r)
-worst, hist, failed = pc.case_saturating_references(make, B=%d, K=%d)
-print(json.dumps(dict(worst=worst, failed=failed, fallbacks=sum(v for k, v in hist.items() if k >= 1000))))
-"""
-    here = os.path.dirname(os.path.abspath(__file__))
-    B, K = (16, 40) if lib is None else (2, 14)
-    res = {}
-    for defer in ("0", "1"):
-        env = dict(os.environ, MPCQ_DEFER=defer, MPCQ_STAGE_MEM="global")
-        out = subprocess.check_output([sys.executable, "-c", code % (here, os.path.dirname(here), lib, B, K)], env=env)
-        res[defer] = json.loads(out.decode().strip().splitlines()[-1])
-    assert res["0"]["failed"] == 0 and res["1"]["failed"] == 0
-    assert res["1"]["fallbacks"] > 0 and res["1"]["worst"] < 1e-7 and res["0"]["worst"] < 1e-7
-
-
 CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log, _free_running_equals_lockstep,
          _command_and_finished, _chunk_cases_on_device, _plant_period_matches_reference_logs, _checkpoint_resume_is_bitwise,
-         _rgp_learn_matches_reference_streams, _static_gp_model_path, _two_phase_period]
+         _rgp_learn_matches_reference_streams, _static_gp_model_path]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.__name__.strip("_") for c in CASES])

@@ -89,7 +89,7 @@ def test_config2_shape_against_oracle():
 
 @pytest.mark.parametrize("shape", [(20, 10, 64, 25), (20, 20, 64, 25), (50, 50, 12, 12)], ids=["N20nb10", "N20nb20", "N50nb50"])
 @pytest.mark.parametrize("precision", [0, 1])
-def test_kernel_variants_agree(precision, shape, monkeypatch):
+def test_kernel_variants_agree(precision, shape):
     """The four step-kernel variants of one precision (stage records in LDS / global memory, shape-specialised -O3 /
     any-shape -O2 instantiation) are the same algorithm: identical working sets, controls equal to rounding.  Every
     shape that has a specialised instance (mpcq_spec.hip: BASELINE configs[1], [2], [4]) is covered."""
@@ -102,13 +102,9 @@ def test_kernel_variants_agree(precision, shape, monkeypatch):
     out = {}
     for mem in ("lds", "global"):
         for generic in (False, True):
-            monkeypatch.setenv("MPCQ_STAGE_MEM", mem)
-            if generic:
-                monkeypatch.setenv("MPCQ_GENERIC", "1")
-            else:
-                monkeypatch.delenv("MPCQ_GENERIC", raising=False)
             try:
-                e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision))
+                e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision,
+                                      tune=dict(stage_mem=mem, generic_kernel=int(generic))))
             except _lib.MpcqError as ex:       # N=50/nb=50 in fp64 does not fit the all-LDS placement
                 assert mem == "lds" and "LDS" in str(ex), ex
                 continue
