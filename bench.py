@@ -24,7 +24,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mpc_quad_ros_amd.engine import Engine  # noqa: E402
+from mpc_quad_ros_amd.engine import (Engine, WARM_PINS, WARM_WRONG, qp_fallback, qp_flip, qp_passes,  # noqa: E402
+                                      qp_warm_exit)
 from mpc_quad_ros_amd.params import PRECISION_F32, PRECISION_F64, EngineConfig, hummingbird, rgp_basis_linspace  # noqa: E402
 from mpc_quad_ros_amd.trajectories import swarm_missions  # noqa: E402
 
@@ -56,7 +57,135 @@ def workload(seed, first_index, B, periods):
     """Continuous operation of the node, per quadrotor: min-snap flights through 3 random waypoints (v_max = a_max = 12, the
     launch defaults), each requested from the end point of the previous one (mpc_quad_ros_amd.trajectories.minsnap_mission),
     long enough for `periods` control periods plus one horizon."""
-    return swarm_missions(seed, first_index, B, periods + 150, v_max=12.0, a_max=12.0)
+    return swarm_missions(seed, first_index, B, periods + 150, max_rows=periods + 150, v_max=12.0, a_max=12.0)
+
+
+def kernel_source_sha16():
+    """Identity of the device code a profile was taken on: hash of the kernel / host sources and the build recipe (the GPU
+    box has no .git).  PMC traffic files carry it; a file from another build is not attached to this run's line."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mpcq_kernels.hpp", "mpcq_api.hip", "mpcq_spec.hip", "Makefile"):
+        with open(os.path.join(ROOT, "mpc_quad_ros_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def dump_engine(e):
+    """Everything a continued run needs: iterate / RGP state / cursors, warm-start flags and statistics, plant states."""
+    return {"state": e.get_state(), "solver": e.get_solver_state(), "x": e.sim_get_state()[0]}
+
+
+def parity_on_workload(dump, refs, N, nb, device, quads=64, periods=30, free_running=False, precision=PRECISION_F64, lib_path=None):
+    """Oracle parity ON THE BENCH WORKLOAD (the checker, never the thing measured): a sample of `quads` quadrotors of a
+    pre-rolled engine (`dump` = dump_engine of it, `refs` its references) -- every quadrotor whose last solve went through
+    the interior point, filled up from the low indices -- is continued host-driven for `periods` control periods on a small
+    engine next to the fp64 CPU oracle: same measurements (the oracle's drag plant), the engine's state overwritten with the
+    oracle's before every step (teacher-forced: each step isolates the arithmetic of one solve, warm-start flags stay the
+    engine's own).  With free_running a second engine runs alongside WITHOUT being overwritten, and so does a twin of the
+    oracle whose iterate was perturbed by 1e-10 (relative) at the start: on this workload some quadrotors (saturated, off
+    their reference by decimetres) sit where the RTI iteration itself amplifies any difference -- the twin measures that
+    amplification per quadrotor, and the free-running engine is judged against it.  Mirrors the loop body
+    src/mpc_controller_node.py:278-318 on both sides.  Returns the worst relative control deviations and what the
+    window covered."""
+    from oracle.oracle import OracleEngine
+    it0 = dump["solver"]["qp_iter"]
+    fb = np.flatnonzero(qp_fallback(it0))
+    sel = np.sort(np.concatenate([fb, np.setdiff1d(np.arange(len(it0)), fb)])[:quads])
+    B = len(sel)
+    kw = dict(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, dt_pred=0.01)
+    if nb:
+        kw.update(basis=rgp_basis_linspace(12.0, nb), theta=[1.0, 0.1, 0.1])
+    o = OracleEngine(EngineConfig(**kw))
+    engines = [Engine(EngineConfig(device=device, precision=precision, **kw), lib_path=lib_path)]
+    twin = None
+    if free_running:
+        engines.append(Engine(EngineConfig(device=device, precision=precision, **kw), lib_path=lib_path))
+        twin = OracleEngine(EngineConfig(**kw))
+    traj, lens = np.ascontiguousarray(refs[0][sel]), np.ascontiguousarray(refs[1][sel])
+    st = {k: np.ascontiguousarray(v[sel]) for k, v in dump["state"].items()}
+    sol = {k: np.ascontiguousarray(v[sel]) for k, v in dump["solver"].items()}
+    o.set_trajectories(traj, lens); o.set_state(**st)
+    if twin is not None:
+        rng = np.random.default_rng(7)
+        stp = dict(st)
+        stp["X"] = st["X"] * (1.0 + 1e-10 * rng.standard_normal(st["X"].shape))
+        stp["U"] = np.clip(st["U"] * (1.0 + 1e-10 * rng.standard_normal(st["U"].shape)), 0.0, 1.0)
+        twin.set_trajectories(traj, lens); twin.set_state(**stp)
+        dev_free, dev_twin = np.zeros(B), np.zeros(B)
+    for e in engines:
+        e.set_trajectories(traj, lens); e.set_state(**st); e.set_solver_state(**sol)
+    x = dump["x"][sel].copy()
+    rel = lambda a, b, floor: float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+    relq = lambda a, b: float((np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-2)).max())
+    out = {"max_rel_dev": 0.0, "max_rel_dev_per_quad": 0.0, "rgp_max_rel_dev": 0.0, "quad_steps": 0, "fallbacks": 0, "flip_marked": 0,
+           "warm_exit_pins": 0, "warm_exit_wrong": 0, "multi_pass": 0, "failed": 0, "saturated_controls": 0,
+           "quads": B, "periods": periods, "fallback_quads_at_dump": int(len(fb)), "mode": "teacher-forced, fp64 CPU oracle"}
+    if free_running:
+        out["free_running_max_rel_dev"] = 0.0
+    e = engines[0]
+    for _ in range(periods):
+        e.set_state(**o.get_state())
+        w, _xp = e.step(x)
+        wo, _ = o.step(x)
+        its = e.get_qp_iter()
+        out["max_rel_dev"] = max(out["max_rel_dev"], rel(w, wo, 1e-3))
+        out["max_rel_dev_per_quad"] = max(out["max_rel_dev_per_quad"], relq(w, wo))
+        if nb:
+            (mu, C), (muo, Co) = e.get_rgp(), o.get_rgp()
+            out["rgp_max_rel_dev"] = max(out["rgp_max_rel_dev"], rel(mu, muo, 1.0), rel(C, Co, 1e-2))
+        if free_running:
+            wf, _ = engines[1].step(x)
+            wt, _ = twin.step(x)
+            dev_free = np.maximum(dev_free, np.abs(wf - wo).max(axis=1))
+            dev_twin = np.maximum(dev_twin, np.abs(wt - wo).max(axis=1))
+        out["quad_steps"] += B
+        out["fallbacks"] += int(qp_fallback(its).sum())
+        out["flip_marked"] += int(qp_flip(its).sum())
+        out["warm_exit_pins"] += int((qp_warm_exit(its) == WARM_PINS).sum())
+        out["warm_exit_wrong"] += int((qp_warm_exit(its) == WARM_WRONG).sum())
+        out["multi_pass"] += int((qp_passes(its) > 1).sum())
+        out["failed"] += int(((e.get_status() & 7) != 0).sum())
+        out["saturated_controls"] += int(((wo <= 0.0) | (wo >= 1.0)).sum())
+        x = o.plant_control_period(x, wo, 0.01, 5e-3)[0]
+    if free_running:
+        # controls live in [0, 1]: absolute deviations are relative to full thrust.  A quadrotor is "contractive" over the window when
+        # the oracle's own 1e-10 twin stays within 1e-7 of it; the others amplify ANY difference (the twin shows by how much).
+        calm = dev_twin < 1e-7
+        out["free_running_max_rel_dev"] = float(dev_free[calm].max()) if calm.any() else 0.0
+        out["free_running_contractive_quads"] = int(calm.sum())
+        out["free_running_sensitive_quads"] = {"count": int((~calm).sum()), "engine_max_dev": float(dev_free[~calm].max()) if (~calm).any() else 0.0,
+                                               "oracle_twin_max_dev": float(dev_twin[~calm].max()) if (~calm).any() else 0.0,
+                                               "engine_over_twin_worst_ratio": float((dev_free[~calm] / np.maximum(dev_twin[~calm], 1e-300)).max()) if (~calm).any() else 0.0}
+        twin.close()
+    for e in engines:
+        e.close()
+    o.close()
+    return out
+
+
+def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps):
+    """One of the other BASELINE configurations as a short lockstep leg (same workload family, pre-rolled): throughput only;
+    their parity is covered by the GPU tests."""
+    e, _cfg = make_engine(B, N, nb, prec, device, 0, 0, refs=(np.ascontiguousarray(refs[0][:B]), np.ascontiguousarray(refs[1][:B])))
+    n_sub = e.plant_substeps(0.01, 5e-3)
+    e.sim_run(preroll, n_sub, 5e-3)
+    e.sim_steps(warmup, n_sub, 5e-3)
+    e.lib.mpcq_synchronize(e.h)
+    t0 = time.perf_counter()
+    e.sim_steps(steps, n_sub, 5e-3)
+    e.lib.mpcq_synchronize(e.h)
+    t1 = time.perf_counter()
+    kt, kl = e.get_kernel_time()
+    its, status = e.get_qp_iter(), e.get_status()
+    st = e.get_tracking_stats()
+    e.close()
+    return {"config": name, "value": B * steps / (t1 - t0), "unit": "control steps/s", "dtype": "f64" if prec == PRECISION_F64 else "f32",
+            "batch": B, "horizon_nodes": N, "rgp_basis": nb, "steps": steps, "warmup": warmup, "preroll_periods": preroll,
+            "ms_per_step": 1e3 * (t1 - t0) / steps, "kernel_avg_ms": 1e3 * kt / max(kl, 1),
+            "algorithmic_gbs": algorithmic_bytes(N, nb, 8 if prec == PRECISION_F64 else 4) * B / (kt / max(kl, 1)) / 1e9,
+            "mean_qp_passes": float(qp_passes(its).mean()), "failed": int(((status & 7) != 0).sum()),
+            "rms_pos_m": float(np.sqrt(st[0] / (3 * max(st[2], 1))))}
 
 
 def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None, periods=1000, refs=None):
@@ -184,7 +313,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1024, help="quadrotors per GPU")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="quadrotors per GPU; default: 1024 on one GPU (BASELINE configs[1]), 8192 per rank under WORLD_SIZE > 1 "
+                         "(configs[3]: 65 536 quadrotors over 8 GPUs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check on the workload")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--nb", type=int, default=10)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
@@ -209,11 +342,17 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"# note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
 
-    B, N, nb = args.batch, args.horizon, args.nb
+    B = args.batch if args.batch > 0 else (1024 if world == 1 else 8192)
+    N, nb = args.horizon, args.nb
     prec = PRECISION_F64 if args.precision == "f64" else PRECISION_F32
     itemsize = 8 if prec == PRECISION_F64 else 4
     periods = args.preroll + args.warmup + args.steps
+    t_gen = time.perf_counter()
     refs = workload(args.seed, rank * B, B, periods)      # host-side generation (worker processes) before the GPU is touched
+    legs = world == 1 and not args.no_configs and (B, N, nb) == (1024, 20, 10)
+    CFG_PRE, CFG_WARM, CFG_STEPS = 300, 5, 20
+    refs_cfg = workload(args.seed, 0, 8192, CFG_PRE + CFG_WARM + CFG_STEPS) if legs else None   # shared by the legs (150 rows >= N skip)
+    t_gen = time.perf_counter() - t_gen
     e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods, refs=refs)
     stats_reduce = "single"
     rccl_hung = False
@@ -259,8 +398,8 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     start = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # where the CPU baseline continues from
-        start = {"state": e.get_state(), "x": e.sim_get_state()[0]}
+    if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_parity):   # where the CPU legs continue from
+        start = dump_engine(e)
     ktime, klaunch = e.get_kernel_time()     # HIP events around the step_kernel launches of the timed region (all of them when steps <= 50, else every 4th)
     kmin, kmax = e.get_kernel_time_minmax()
     its = e.get_qp_iter()
@@ -298,14 +437,16 @@ def main():
         k_avg = ktime / max(klaunch, 1)
         bytes_launch = algorithmic_bytes(N, nb, itemsize) * B
         achieved = bytes_launch / k_avg / 1e9
-        flops_launch = algorithmic_flops(N, nb, float((its % 1000).mean())) * B
+        flops_launch = algorithmic_flops(N, nb, float(qp_passes(its).mean())) * B
         out = {
             "metric": "batched MPC+RGP control steps/sec (N=20 horizon)" if N == 20 else f"batched MPC+RGP control steps/sec (N={N} horizon)",
             "value": value, "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] per GPU: batch {B} hummingbird quadrotors, N={N}, RGP {nb} basis pts/axis, "
-                                   "closed loop with on-device drag plant, continuous operation on seeded random-waypoint min-snap flights (3 waypoints each, v_max=a_max=12)",
+            "config": {"workload": (f"BASELINE configs[1]: batch {B} hummingbird quadrotors" if world == 1 else
+                                    f"BASELINE configs[3]: swarm of {B * world} hummingbird quadrotors sharded over {world} GPUs ({B} per GPU)")
+                                   + f", N={N}, RGP {nb} basis pts/axis, closed loop with on-device drag plant, continuous operation on seeded "
+                                     "random-waypoint min-snap flights (3 waypoints each, v_max=a_max=12)",
                        "batch_per_gpu": B, "global_batch": B * world, "horizon_nodes": N, "rgp_basis": nb, "preroll_periods": args.preroll,
                        "parallelism": f"shard{world}" if world > 1 else "single", "threads_per_quad": 64,
                        "stats_reduce": stats_reduce, "rccl_ok": world == 1 or stats_reduce == "rccl"},
@@ -321,30 +462,37 @@ def main():
                          "vector_flops": {"achieved_tflops": flops_launch / k_avg / 1e12,
                                           "peak_tflops": FP_VECTOR_PEAK[args.precision],
                                           "frac": flops_launch / k_avg / 1e12 / FP_VECTOR_PEAK[args.precision]}},
-            "solver": {"mean_qp_passes": float((its % 1000).mean()), "max_qp_passes": int((its % 1000).max()),
-                       "ipm_fallbacks_last_step": int((its >= 1000).sum()), "failed": int((status != 0).sum())},
+            "solver": {"mean_qp_passes": float(qp_passes(its).mean()), "max_qp_passes": int(qp_passes(its).max()),
+                       "ipm_fallbacks_last_step": int(qp_fallback(its).sum()), "failed": int(((status & 7) != 0).sum())},
+            "host_generation_s": t_gen,
             "tracking": {"rms_pos_m": float(np.sqrt(stats[0] / (3 * max(stats[2], 1)))), "steps": float(stats[2]),
                          "max_pos_err_m": float(np.sqrt(stats[3])), "failed_instances": float(stats[4])},
         }
+        # HBM bytes per launch from rocprofv3 --pmc passes (profiles/README.md): attached only when the profile was taken on
+        # THIS build (source hash) with THIS command line; otherwise null -- a number from another build is not this run's traffic.
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{args.precision}.json")))
-        pmc = cands[-1] if cands and (B, N, nb) == (1024, 20, 10) else ""
-        if pmc and os.path.exists(pmc):   # HBM bytes per launch from rocprofv3 --pmc passes of this same command (profiles/README.md)
-            with open(pmc) as f:
-                t = json.load(f)
-            out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-            out["roofline"]["traffic_source"] = t.get("source")
-            if args.precision == "f64":
-                out["roofline"]["traffic_note"] = ("fp64 keeps the per-stage records (38.6 KB per instance) in global memory, streamed through L2, so "
-                                                   "that 4 instead of 2 instances fit a CU; every further working set / interior-point iteration of a "
-                                                   "quadrotor re-reads them, so the traffic grows with the pass count of the launch (DESIGN.md section 3.1)")
+        sha = kernel_source_sha16()
+        key = {"steps": args.steps, "warmup": args.warmup, "preroll": args.preroll, "seed": args.seed, "batch": B, "N": N, "nb": nb,
+               "precision": args.precision}
+        out["roofline"]["traffic_note"] = f"no PMC profile of build {sha} for this command line under profiles/"
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_*.json"))):
+            try:
+                with open(f) as fh:
+                    t = json.load(fh)
+            except (OSError, ValueError):
+                continue
+            if t.get("source_sha16") == sha and t.get("args") == key:
+                out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = {"file": os.path.basename(f), "source_sha16": sha, "command": t.get("command"),
+                                                     "commit": t.get("commit")}
+                out["roofline"]["traffic_note"] = t.get("note", "")
         if world == 1 and not args.no_alt:
             # Same K periods as ONE launch in which every quadrotor runs through its periods without waiting for the
             # slowest member of the batch (mpcq_sim_run): the lockstep figure above is what a controller fed by live
             # measurements gets per tick, this one is the capacity of the device as a closed-loop swarm simulator.
             x_lock, w_lock = e.sim_get_state()
             e.close()
-            e3, _ = make_engine(B, N, nb, prec, local_rank, 0, args.seed, periods=periods, refs=refs)
+            e3, _ = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods, refs=refs)
             e3.sim_run(args.preroll + args.warmup, n_sub, 5e-3)
             e3.lib.mpcq_synchronize(e3.h)
             ta = time.perf_counter()
@@ -369,14 +517,25 @@ def main():
             e2.lib.mpcq_synchronize(e2.h)
             tb = time.perf_counter()
             k2, l2 = e2.get_kernel_time()
-            out["alt_precision"] = {"dtype": alt, "value": B * args.steps / (tb - ta), "unit": "control steps/s",
-                                    "kernel_avg_ms": 1e3 * k2 / max(l2, 1),
-                                    "note": "same workload with the QP arithmetic in the other precision.  f32 (all-LDS working set): relative control "
-                                            "deviation vs the fp64 oracle <= 1e-4 on every warm-started solve of the six reference logs (median 2e-6); "
-                                            "interior-point fallback solves reach 1.2e-4..1.5e-4 on two logs and 1.2e-3 on one tumbling step "
-                                            "(profiles/r2_f32_log_report.json, DESIGN.md section 5).  f64 (stage records in global memory): <= 3e-10.  "
-                                            "Both place 4 quadrotors per CU"}
+            st2 = e2.get_status()
+            out["experimental_f32" if alt == "f32" else "alt_precision"] = {"dtype": alt, "value": B * args.steps / (tb - ta), "unit": "control steps/s",
+                                    "kernel_avg_ms": 1e3 * k2 / max(l2, 1), "failed": int(((st2 & 7) != 0).sum()),
+                                    "low_accuracy_last_step": int((st2 == 8).sum()),
+                                    "note": "same workload with the QP arithmetic in the other precision.  f32 is an EXPERIMENTAL mode (include/mpcq.h): "
+                                            "it meets the 1e-4 control budget on solves that succeed from their warm start; solves that went through "
+                                            "the interior point are reported per instance as MPCQ_SOLVE_LOW_ACCURACY (counted here for the last step).  "
+                                            "f64 is the reference's own arithmetic (<= 1e-7 vs the fp64 oracle)"}
             e2.close()
+        if legs:
+            # the other BASELINE configurations, reachable from the driver's command: short lockstep legs after the headline
+            out["configs"] = [
+                config_leg("configs[2]: batch 8192, N=20, RGP 20 basis pts", refs_cfg, 8192, 20, 20, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
+                config_leg("configs[3] per rank: batch 8192 of 65536, N=20, RGP 10 basis pts", refs_cfg, 8192, 20, 10, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
+                config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
+                config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F32, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
+            ]
+        if world == 1 and not args.no_parity:
+            out["parity_on_workload"] = parity_on_workload(start, refs, N, nb, local_rank, quads=64, periods=30)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, nb, args.seed, refs=refs, start=start)
         print(json.dumps(out))

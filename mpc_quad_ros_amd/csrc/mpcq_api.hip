@@ -18,7 +18,11 @@
 
 namespace mpcq {   // mpcq_spec.hip, one translation unit per specialised shape
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
+#ifdef MPCQ_CHECKED   // the checked build compiles for tens of minutes per specialised shape: only the headline shape has one there
+#define MPCQ_SPEC_SHAPES(X) X(20, 10)
+#else
 #define MPCQ_SPEC_SHAPES(X) X(20, 10) X(20, 20) X(50, 50)   // BASELINE configs[1] (and [3] per rank), configs[2], configs[4]
+#endif
 #define MPCQ_DECL(n, nb) StepFn<double> spec_step_f64_##n##_##nb(bool gab, bool run); StepFn<float> spec_step_f32_##n##_##nb(bool gab, bool run);
 MPCQ_SPEC_SHAPES(MPCQ_DECL)
 #undef MPCQ_DECL
@@ -192,7 +196,7 @@ struct EngineT : mpcq_engine {
 
   ~EngineT() override {
     DeviceGuard guard(cfg.device);
-    void* ptrs[] = {st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
+    void* ptrs[] = {st.chk, st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
                     st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -342,6 +346,9 @@ struct EngineT : mpcq_engine {
 #ifdef MPCQ_PROFILE
     if ((rc = dalloc(st.prof, Bz * mpcq::PF_N))) return rc;
 #endif
+#ifdef MPCQ_CHECKED
+    if ((rc = dalloc(st.chk, 16))) return rc;
+#endif
     st.tlen = d_tlen; st.traj = nullptr; st.x_meas = d_xin;
     // Placement of the per-stage records (AB'', c, qv): LDS when the whole batch is resident at once that way,
     // otherwise global memory (L2 / MALL) if that lets more instances share a CU.  mpcq_config.tune.stage_mem overrides.
@@ -421,6 +428,26 @@ struct EngineT : mpcq_engine {
   }
   int set_params(const double* mu) override { return nb ? h2q(st.mu, mu, (size_t)B * 3 * nb) : 0; }
 
+  // Checked build: every call that launched the step / regress kernel ends here -- the first out-of-range index or partial EXEC
+  // mask the device code recorded turns the call into an error that names it (region tag, index, valid range, lane, workgroup,
+  // program counter relative to the kernel entry recorded by workgroup 0).
+  int chk_after() {
+#ifdef MPCQ_CHECKED
+    int r[16];
+    HIP_TRY(hipMemcpyAsync(r, st.chk, sizeof(r), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (r[0]) {
+      HIP_TRY(hipMemsetAsync(st.chk, 0, sizeof(r), stream));
+      const unsigned long long pc = ((unsigned long long)(unsigned)r[8] << 32) | (unsigned)r[7], entry = ((unsigned long long)(unsigned)r[10] << 32) | (unsigned)r[9];
+      char buf[320];
+      snprintf(buf, sizeof(buf), "checked build: %s tag %d index %d outside [%d, %d) on lane %d of workgroup %d, pc - entry = 0x%llx",
+               r[1] >= mpcq::CK_EXEC ? "partial EXEC mask at cross-lane site," : "out-of-range access, region", r[1], r[2], r[3], r[4], r[5], r[6],
+               (unsigned long long)(pc - entry));
+      return fail(MPCQ_ERR_DEVICE, buf);
+    }
+#endif
+    return 0;
+  }
   int base_mode() const { return (cfg.flags & MPCQ_FLAG_STATIC_GP) ? mpcq::MODE_STATIC_GP : 0; }
   void launch_period(const mpcq::DevState<T>& s, int mode) { hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode); }
   int launch_step(int mode) {
@@ -437,7 +464,7 @@ struct EngineT : mpcq_engine {
     st.x_meas = d_xin;
     if ((rc = launch_step(0))) return rc;
     HIP_TRY(hipStreamSynchronize(stream));
-    return 0;
+    return chk_after();
   }
   int get_x(int stage, double* out) override {
     if (stage < 0 || stage > N) return fail(MPCQ_ERR_INVALID, "stage out of range");
@@ -477,7 +504,7 @@ struct EngineT : mpcq_engine {
     hipLaunchKernelGGL(mpcq::regress_kernel<T>, dim3(B), dim3(64), lds_bytes, stream, m, st, d_vb, d_ad);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
-    return 0;
+    return chk_after();
   }
   int get_rgp(double* mu, double* C) override {
     int rc;
@@ -501,7 +528,7 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipStreamSynchronize(stream));
     std::memcpy(w_out, h_pin + nx, nw * sizeof(double));
     if (x_pred_out) std::memcpy(x_pred_out, h_pin + nx + nw, nx * sizeof(double));
-    return 0;
+    return chk_after();
   }
   int step_device(const double* d_x, double* d_w) override {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_step_device_async needs mpcq_set_trajectories first");
@@ -513,7 +540,7 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev1, stream));
     timed = true;
-    return 0;
+    return chk_after();   // (synchronises in the checked build only)
   }
   int sim_reset(const double* x0) override { return h2d(d_xs, x0, (size_t)B * 13); }
   int sim_steps(int K, int n_sub, double sim_dt) override {
@@ -553,7 +580,7 @@ struct EngineT : mpcq_engine {
       kmin = std::min(kmin, (double)ms * 1e-3); kmax = std::max(kmax, (double)ms * 1e-3);
     }
     if (!nev) kmin = 0;
-    return 0;
+    return chk_after();
   }
   int sim_run(int K, int n_sub, double sim_dt) override {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_sim_run needs mpcq_set_trajectories first");
@@ -574,7 +601,7 @@ struct EngineT : mpcq_engine {
     HIP_TRY(hipEventElapsedTime(&ms, kev[0], kev[1]));
     ktime = kmin = kmax = ms * 1e-3;
     klaunches = 1;
-    return 0;
+    return chk_after();
   }
   int sim_get(double* x, double* w) override {
     int rc;
@@ -686,7 +713,11 @@ struct EngineT : mpcq_engine {
 extern "C" {
 
 const char* mpcq_last_error(void) { return g_err.c_str(); }
+#ifdef MPCQ_CHECKED
+const char* mpcq_version(void) { return "mpcq 0.3 (gfx950, CHECKED diagnostic build)"; }
+#else
 const char* mpcq_version(void) { return "mpcq 0.3 (gfx950)"; }
+#endif
 
 int mpcq_create(const mpcq_config* c, mpcq_engine** out) { return mpcq_create_sized(c, sizeof(mpcq_config), out); }
 int mpcq_create_sized(const mpcq_config* c_in, uint64_t cfg_size, mpcq_engine** out) {

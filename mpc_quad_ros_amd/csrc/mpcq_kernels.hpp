@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #ifdef MPCQ_EMU_DEBUG
 #include <cstdio>
 #endif
@@ -75,7 +76,77 @@ namespace mpcq {
 #ifndef MPCQ_COLD
 #define MPCQ_COLD __device__ inline
 #endif
+template <typename T> struct alignas(16) V4 { T a, b, c, d; };
 constexpr int NX = 13, NU = 4, NY = 17;
+
+extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base), shared by the kernels and their out-of-line phases
+
+// ------------------------------------------------------------------ checked build (-DMPCQ_CHECKED, libmpcq_checked.so)
+// Diagnostic build for the GPU (AddressSanitizer is not available on the device here): every pointer of the step kernel
+// is a fat pointer P<T> = (base, valid index range, region tag); every access checks its index against the region -- the LDS
+// workspace [0, qtotal), the double block [0, dbytes/8), the per-instance global record [0, gtotal), the trajectory
+// [0, Tmax 13), the state records -- and every cross-lane operation (v_readlane, DPP, permlane swaps, MFMA) checks that
+// the wavefront executes it with a full EXEC mask.  The first violation is recorded in DevState::chk (tag, index, range,
+// lane, workgroup, program counter relative to the kernel entry) and the access is redirected to a sink, so the launch
+// completes and the host reports it (mpcq_api.hip: every launch of the checked build is followed by a read of the record).
+// In the product build P<T> is T* and none of this exists.
+enum : int { CK_LDS_D = 1, CK_LDS_Q, CK_STAGE, CK_X, CK_U, CK_TRAJ, CK_YREF, CK_YREFN, CK_MU, CK_C, CK_XPP, CK_W, CK_XPRED, CK_STATS, CK_RUNX,
+             CK_XMEAS, CK_BASIS, CK_KXINV, CK_NULL, CK_EXEC = 64 };
+#ifdef MPCQ_CHECKED
+constexpr int CK_HDR = 16;   // bytes at the base of the dynamic LDS block: the address of the violation record
+__device__ inline int* ck_rec() { return *reinterpret_cast<int**>(smem_raw); }
+__device__ inline void ck_report(int tag, long i, long lo, long hi) {
+  int* r = ck_rec();
+  if (r && atomicCAS(&r[0], 0, 1) == 0) {
+    r[1] = tag; r[2] = (int)i; r[3] = (int)lo; r[4] = (int)hi; r[5] = (int)threadIdx.x; r[6] = (int)blockIdx.x;
+    const unsigned long long pc = __builtin_amdgcn_s_getpc();
+    r[7] = (int)(unsigned)pc; r[8] = (int)(unsigned)(pc >> 32);
+  }
+}
+__device__ inline void ck_exec(int site) {
+  const unsigned long long ex = __builtin_amdgcn_read_exec();
+  if (ex != ~0ull) ck_report(CK_EXEC + site, (long)(ex >> 32), 0, (long)(unsigned)ex);
+}
+template <typename T> struct CkPtr {
+  using V = typename std::remove_const<T>::type;
+  T* p; long lo, hi; int tag;
+  mutable V sink;
+  __device__ CkPtr() : p(nullptr), lo(0), hi(0), tag(CK_NULL), sink() {}
+  __device__ CkPtr(decltype(nullptr)) : CkPtr() {}
+  __device__ CkPtr(T* p_, long n, int tag_) : p(p_), lo(0), hi(p_ ? n : 0), tag(tag_), sink() {}
+  __device__ CkPtr(T* p_, long lo_, long hi_, int tag_) : p(p_), lo(lo_), hi(hi_), tag(tag_), sink() {}
+  template <typename U> __device__ CkPtr(const CkPtr<U>& o) : p(o.p), lo(o.lo), hi(o.hi), tag(o.tag), sink() {}
+  __device__ explicit operator bool() const { return p != nullptr; }
+  // element i (and the n - 1 behind it) inside the region?
+  __device__ bool ok(long i, long n = 1) const {
+    if (i >= lo && i + n <= hi) return true;
+    ck_report(tag, i, lo, hi);
+    return false;
+  }
+  template <typename I> __device__ T& operator[](I i) const { return ok((long)i) ? p[(long)i] : const_cast<T&>(static_cast<const V&>(sink)); }
+  template <typename I> __device__ CkPtr operator+(I o) const { return CkPtr(p + (long)o, lo - (long)o, hi - (long)o, tag); }
+};
+template <typename T> using P = CkPtr<T>;
+template <typename T> __device__ inline P<T> mk(T* p, long n, int tag) { return P<T>(p, n, tag); }
+// 128-bit view of four consecutive elements
+template <typename T> __device__ inline V4<typename std::remove_const<T>::type> ld4(const P<T>& b, long off) {
+  if (b.ok(off, 4)) return *reinterpret_cast<const V4<typename std::remove_const<T>::type>*>(b.p + off);
+  return V4<typename std::remove_const<T>::type>{};
+}
+template <typename T> __device__ inline void st4(const P<T>& b, long off, const V4<T>& v) {
+  if (b.ok(off, 4)) *reinterpret_cast<V4<T>*>(b.p + off) = v;
+}
+#define CK_EXEC_FULL(site) ck_exec(site)
+#else
+constexpr int CK_HDR = 0;
+template <typename T> using P = T*;
+template <typename T> __device__ inline T* mk(T* p, long, int) { return p; }
+template <typename T> __device__ inline V4<typename std::remove_const<T>::type> ld4(T* b, long off) {
+  return *reinterpret_cast<const V4<typename std::remove_const<T>::type>*>(b + off);
+}
+template <typename T> __device__ inline void st4(T* b, long off, const V4<T>& v) { *reinterpret_cast<V4<T>*>(b + off) = v; }
+#define CK_EXEC_FULL(site)
+#endif
 constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
 constexpr int VS = 16;           // stride of state-sized QP vectors (internal order, 13 used)
 constexpr int ABS = NX * ABW;    // per-stage stride of AB'
@@ -177,9 +248,8 @@ struct DevState {
   int run_steps, run_nsub;   // control periods per launch, plant substeps per period
   double run_dt;    // plant substep
   unsigned long long* prof;   // [B][PF_N] (diagnostic build only)
+  int* chk;         // [16] first violation found by the checked build (-DMPCQ_CHECKED), nullptr otherwise
 };
-
-extern __shared__ unsigned char smem_raw[];   // dynamic LDS (16-byte aligned base), shared by the kernels and their out-of-line phases
 
 // ------------------------------------------------------------------ LDS layout
 // doubles first (offsets in doubles from the LDS base), then the TQ region (offsets in TQ elements
@@ -250,10 +320,9 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   L.qtotal = o;
   return L;
 }
-template <typename TQ> __host__ __device__ inline size_t lds_bytes(const Lds& L) { return (size_t)L.dbytes + (size_t)L.qtotal * sizeof(TQ); }
+template <typename TQ> __host__ __device__ inline size_t lds_bytes(const Lds& L) { return (size_t)CK_HDR + (size_t)L.dbytes + (size_t)L.qtotal * sizeof(TQ); }
 
 // ------------------------------------------------------------------ small helpers
-template <typename T> struct alignas(16) V4 { T a, b, c, d; };
 
 // Ablation build only (BASELINE configs[4] "fp32 vs bf16 tolerance", csrc/Makefile `variant NAME=bf16`): what is STORED
 // -- the stage records AB'', gaps, cost gradients, and the RGP mean / covariance between steps -- is rounded to bfloat16
@@ -282,14 +351,14 @@ __device__ inline int lane_id() {
   return t;
 }
 // lane broadcast: `lane` must be wave-uniform (a constant after unrolling) -> v_readlane_b32 into an SGPR
-__device__ inline int bc(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ inline int bc(int v, int lane) { CK_EXEC_FULL(1); return __builtin_amdgcn_readlane(v, lane); }
 __device__ inline float bc(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ inline double bc(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
 // DPP lane permutes inside 16-lane rows (quad_perm / row_ror), no LDS involved
-template <int CTRL> __device__ inline int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ inline int dpp(int v) { CK_EXEC_FULL(2); return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
 template <int CTRL> __device__ inline float dpp(float v) { return __int_as_float(dpp<CTRL>(__float_as_int(v))); }
 template <int CTRL> __device__ inline double dpp(double v) {
   return __hiloint2double(dpp<CTRL>(__double2hiint(v)), dpp<CTRL>(__double2loint(v)));
@@ -298,6 +367,7 @@ template <int CTRL> __device__ inline double dpp(double v) {
 // outputs hold rows (0,0,2,2) and (1,1,3,3), after v_permlane32_swap rows (0,1,0,1) and (2,3,2,3) -- their sum is the
 // butterfly step on every lane, no select (gfx950; no LDS, no SGPR round trip)
 __device__ inline float hsum(float v) {
+  CK_EXEC_FULL(3);
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   const unsigned b = (unsigned)__float_as_int(v);
   const u2 r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
@@ -307,6 +377,7 @@ __device__ inline float hsum(float v) {
   return __int_as_float((int)q[0]) + __int_as_float((int)q[1]);
 }
 __device__ inline double hsum(double v) {
+  CK_EXEC_FULL(3);
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
   const u2 rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
@@ -368,12 +439,14 @@ template <typename TQ> __device__ inline void l2g(TQ x, int h, TQ (&v)[4]) {
 }
 #ifndef MPCQ_NO_MFMA
 __device__ inline void mfma(float (&acc)[4], float a, float b) {
+  CK_EXEC_FULL(4);
   typedef float f4 __attribute__((ext_vector_type(4)));
   f4 cc = {acc[0], acc[1], acc[2], acc[3]};
   cc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, cc, 0, 0, 0);
   acc[0] = cc[0]; acc[1] = cc[1]; acc[2] = cc[2]; acc[3] = cc[3];
 }
 __device__ inline void mfma(double (&acc)[4], double a, double b) {
+  CK_EXEC_FULL(4);
   typedef double d4 __attribute__((ext_vector_type(4)));
   d4 cc = {acc[0], acc[1], acc[2], acc[3]};
   cc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cc, 0, 0, 0);
@@ -398,19 +471,19 @@ template <typename T> __device__ inline void mfma(T (&acc)[4], T a, T b) {
 }
 #endif
 // A state-sized vector rides in column 14 of a tile: lane (h, 14) holds slots RI(s,h), s = 0..3.
-__device__ inline void vl_load(const float* base, int h, float (&v)[4]) {   // slots 4h..4h+3: one 128-bit read
-  const V4<float> t = *reinterpret_cast<const V4<float>*>(base + 4 * h);
+template <typename PT> __device__ inline void vl_load(PT base, int h, float (&v)[4]) {   // slots 4h..4h+3: one 128-bit read
+  const V4<float> t = ld4(base, 4 * h);
   v[0] = t.a; v[1] = t.b; v[2] = t.c; v[3] = t.d;
 }
-__device__ inline void vl_store(float* base, int h, const float (&v)[4]) {
+template <typename PT> __device__ inline void vl_store(PT base, int h, const float (&v)[4]) {
   V4<float> t; t.a = v[0]; t.b = v[1]; t.c = v[2]; t.d = v[3];
-  *reinterpret_cast<V4<float>*>(base + 4 * h) = t;
+  st4(base, 4 * h, t);
 }
-__device__ inline void vl_load(const double* base, int h, double (&v)[4]) {
+template <typename PT> __device__ inline void vl_load(PT base, int h, double (&v)[4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) v[s] = base[h + 4 * s];
 }
-__device__ inline void vl_store(double* base, int h, const double (&v)[4]) {
+template <typename PT> __device__ inline void vl_store(PT base, int h, const double (&v)[4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) base[h + 4 * s] = v[s];
 }
@@ -428,9 +501,9 @@ template <typename TQ> struct KMaj {
       str[s] = k < NX ? ABS : 0;
     }
   }
-  __device__ inline void load(const TQ* P, int i, TQ (&o)[4]) const {
+  template <typename PT> __device__ inline void load(PT Pb, int i, TQ (&o)[4]) const {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) o[s] = P[off[s] + i * str[s]];
+    for (int s = 0; s < 4; ++s) o[s] = Pb[off[s] + i * str[s]];
   }
 };
 // row-major operand: lane (h,c) <- M[c][RI(s,h)] for a row-major matrix of `rows` rows at `base` (stage stride
@@ -442,7 +515,7 @@ template <typename TQ> struct RMaj {
     str = c < rows ? sst : 0;
     hh = h;
   }
-  __device__ inline void load(const TQ* P, int i, TQ (&o)[4]) const { vl_load(P + off + i * str, hh, o); }
+  template <typename PT> __device__ inline void load(PT Pb, int i, TQ (&o)[4]) const { vl_load(Pb + (off + i * str), hh, o); }
 };
 // Operands are fetched PD stages ahead of their use: one stage hides the LDS latency, the global stage
 // records need more.  q[0] is the current stage; shift() retires it.
@@ -493,9 +566,9 @@ template <typename T> struct QC {
 // writes the record the sensitivity pass needs: x(13) | d vdot/dq (3x4) | d vdot/dv (3x3) | R[:,2].
 // GP term: m_d(s) = sum_j alpha_dj sf2 exp(-(s - X_j)^2 L2inv / 2), alpha = Kx^-1 mu.
 // gd >= 0: this lane sums only GP axis gd and the three lanes of a stage exchange the sums through gx (LDS).
-template <typename T, typename TG>
+template <typename T, typename TG, typename PA, typename PB, typename PS, typename PG = TG*>
 __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const TG* sf2, const T* x, const T* u,
-                                  const TG* alpha, const TG* basis, T* f, T* sub, int gd = -1, TG* gx = nullptr) {
+                                  PA alpha, PB basis, T* f, PS sub, int gd = -1, PG gx = nullptr) {
   const T* q = x + 3; const T* v = x + 7; const T* r = x + 10;
   T R[9];
   rotmat(q, R);
@@ -513,7 +586,7 @@ __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const
   f[11] = (-m.tmax * tx + (m.J[2] - m.J[0]) * r[2] * r[0]) * m.iJ[1];
   f[12] = (m.tmax * tz + (m.J[0] - m.J[1]) * r[0] * r[1]) * m.iJ[2];
   T mg[3] = {0, 0, 0}, mp[3] = {0, 0, 0};
-  const bool gp = alpha != nullptr;
+  const bool gp = (bool)alpha;
   if (gp) {
     T vb[3];
 #pragma unroll
@@ -670,13 +743,13 @@ template <typename C, typename M> __device__ inline int cNB(const M& m) { return
 // pass 1: lane (triple) per interval, 4 RK substages in TQ; writes records + gap c_i = Phi_i - X_{i+1}
 // (the part X_i - X_{i+1} of the gap is formed in double)
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* A, const Lds& L, bool gp) {
+MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, const Lds& L, bool gp) {
   const int N = cN<C>(m), lane = lane_id();
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
   // with the GP in the model the three axis sums (nb exps each) of a stage go to three neighbouring lanes
   const int per = gp ? 3 : 1, lanes_used = gp ? 63 : 64, spr = lanes_used / per;   // stages per round
-  TQ* gx = S + L.gx + (lane / 3) * 8;   // LDS exchange scratch
+  P<TQ> gx = S + (L.gx + (lane / 3) * 8);   // LDS exchange scratch
   for (int base = 0; base < N; base += spr) {
     const int il = lane / per, d = lane - il * per;
     const bool valid = lane < lanes_used && base + il < N;
@@ -687,13 +760,13 @@ MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* 
     for (int j = 0; j < NX; ++j) x[j] = (TQ)D[L.X + i * NX + j];
 #pragma unroll
     for (int j = 0; j < NU; ++j) u[j] = (TQ)D[L.U + i * NU + j];
-    const TQ* al = gp ? S + L.alpha : nullptr;
-    TQ* sub = (valid && d == 0) ? S + L.sub + i * SUBS : nullptr;
+    const P<TQ> al = gp ? S + L.alpha : P<TQ>(nullptr);
+    const P<TQ> sub = (valid && d == 0) ? S + (L.sub + i * SUBS) : P<TQ>(nullptr);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] = 0; xt[j] = x[j]; }
     MPCQ_RK_LOOP
     for (int s = 0; s < 4; ++s) {   // acc = k1 + 2 k2 + 2 k3 + k4, next point x + {h/2, h/2, h} k
-      model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + s * SUBW : nullptr, gd, gx);
+      model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + s * SUBW : P<TQ>(nullptr), gd, gx);
       const TQ wa = (s == 0 || s == 3) ? TQ(1) : TQ(2), hc = s == 2 ? h : h / 2;
 #pragma unroll
       for (int j = 0; j < NX; ++j) { acc[j] += wa * k[j]; xt[j] = x[j] + hc * k[j]; }
@@ -709,7 +782,7 @@ MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, const double* D, TQ* S, TQ* 
 }
 // pass 2: item = (interval i, column j of [A|B], j = 3..16) -> AB'[i][r][j-3]
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
+MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L) {
   const int N = cN<C>(m);
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
@@ -727,7 +800,7 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
       if (j - NX == c) { jur[0] = qc.tmax * qc.yf[c] * qc.iJ[0]; jur[1] = -qc.tmax * qc.xf[c] * qc.iJ[1]; jur[2] = qc.tmax * qc.zl[c] * qc.iJ[2]; }
     MPCQ_SENS_LOOP
     for (int s = 0; s < 4; ++s) {
-      const TQ* sub = S + L.sub + i * SUBS + s * SUBW;
+      const P<TQ> sub = S + (L.sub + i * SUBS + s * SUBW);
       const TQ hs = s == 0 ? TQ(0) : (s == 3 ? h : h * TQ(0.5)), ws = (s == 0 || s == 3) ? TQ(1) : TQ(2);
 #pragma unroll
       for (int r = 0; r < NX; ++r) Z[r] = ((r == j) ? TQ(1) : TQ(0)) + hs * Sp[r];
@@ -754,7 +827,7 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
 #pragma unroll
       for (int r = 0; r < NX; ++r) { acc[r] += ws * Sn[r]; Sp[r] = Sn[r]; }
     }
-    TQ* AB = A + L.AB + i * ABS;
+    const P<TQ> AB = A + (L.AB + i * ABS);
 #pragma unroll
     for (int r = 0; r < NX; ++r) AB[o2i(r) * ABW + jp] = st16(((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r]);
   }
@@ -791,7 +864,7 @@ __host__ __device__ inline int GI(int i) { return (i >> 2) * VS + 10 + (i & 3); 
 
 // forward rollout dx_{i+1} = A dx_i + B z_i (+ c_i); dx_0 taken from S[dxo + 0..15]
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dxo, int zo, bool with_c) {
+MPCQ_COLD void rollout(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, int dxo, int zo, bool with_c) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[zo + i];
   __syncthreads();
@@ -833,7 +906,7 @@ MPCQ_COLD void rollout(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dx
 
 // adjoint sweep: grad = d/dz of the QP objective at (dx(z), z)
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_COLD void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
+MPCQ_COLD void adjoint(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.wq + 2 * VS + (i & 3)] * S[L.z + i] + S[L.r0 + i];
   __syncthreads();
@@ -871,7 +944,7 @@ MPCQ_COLD void adjoint(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L) {
 
 // backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, bool polish) {
+MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, bool polish) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
@@ -888,7 +961,7 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
       km.load(A, i - PD > 0 ? i - PD : 0, qa[PD]);
       const TQ rvc = S[L.vin + i * VS + c];                    // rho_j on lane column 10 + j
       const TQ kk = S[L.K + i * KS + h * ABW + c];             // K[h][c]
-      const V4<TQ> li = *reinterpret_cast<const V4<TQ>*>(S + L.Linv + i * 16 + lj * 4);
+      const V4<TQ> li = ld4(S, L.Linv + i * 16 + lj * 4);
       const TQ rtj = S[L.rt + i * NU + lj];
       TQ pv[4];
       l2g<TQ>(pc, h, pv);
@@ -924,7 +997,7 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, TQ* S, TQ* A, const L
 // the sum over the four lane rows (hsum).  The result arrives lane-indexed (lane (.,c) holds row c); the next product needs
 // it group-uniform again: the inputs go through four v_readlane, the state through the LDS vector that the sweep writes anyway.
 template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, int dzo PF_ARG) {
+MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, int dzo PF_ARG) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
   constexpr bool F64 = sizeof(TQ) == 8;
   const Sel<TQ> sel(h);
@@ -990,8 +1063,8 @@ MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& 
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L PF_ARG, TQ* gscale = nullptr, TQ* mrows = nullptr,
-                                      TQ* pstore = nullptr, int start = -1) {
+MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L PF_ARG, TQ* gscale = nullptr, P<TQ> mrows = nullptr,
+                                      P<TQ> pstore = nullptr, int start = -1) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
@@ -1029,15 +1102,16 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
     mT[s] = (cp && rq) ? TQ(1) : TQ(0);
     toff[s] = L.sT + (cp ? (c - 10) * VS : 0) + (row < VS ? row : 0);
   }
-  // operands of the k=4 tile M^T K: M[h][c] (c < 10: F''[10+h][c]; position c: T1''[c][10+h]) and K[h][c]
-  const int moff = cq ? L.sF + h * VS + c : (cp ? L.sT + (c - 10) * VS + 10 + h : L.sF);
+  // Roles in the solve behind the stage Hessian: EVERY lane row solves column c of M (c < 13; M[j][c] = F''[10+j][c] for c < 10,
+  // T1''[c][10+j] for the position columns), so lane (h,c) has both operands of the k=4 tile M^T K -- M[h][c] and K[h][c] -- in
+  // registers, and p_i[c] lane-indexed: nothing of the P update waits for an LDS round trip.  Lanes (0,13), (0,14), (0,15), (1,13)
+  // solve for the unit vectors: rows 0..3 of Lambda^-1 and the feed-forward k_i.
   const TQ mmask = c < NX ? TQ(1) : TQ(0);
-  // which accumulator registers hold tile rows 10..13 (F'': M and Lambda rows) / 10..12 (T1'': position rows)
-  const int b3 = lane < NX ? lane : 0, vj = (lane >= NX && lane < NY) ? lane - NX : 0;
+  const int b3 = c < NX ? c : 0;
+  const bool inv = c >= NX && (h == 0 || (h == 1 && c == NX));
+  const int vj = h == 0 ? (c >= NX ? c - NX : 0) : 3;
   const int m3off = b3 < 10 ? L.sF + b3 : L.sT + (b3 - 10) * VS + 10, m3str = b3 < 10 ? VS : 1;   // M[j][b3]
   const int tboff = b3 < 10 ? L.stv + VS + b3 : L.stv + b3;                                       // (A^T p)[b3]
-  const int o4str = lane < NX ? ABW : 1;
-  const TQ o4sgn = lane < NX ? TQ(-1) : TQ(1), tbm = lane < NX ? TQ(1) : TQ(0);
   TQ cur[4], nxt[4];
   // affine: pad column 14 of the operand carries the gap (S[L.Dx], prepared by the caller), so that P c comes out of the
   // product P AB'' for free
@@ -1049,7 +1123,6 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
   };
   km.load(A, first, cur);
   if (affine) with_gap(first, cur);
-  if (lane < VS) S[L.spv + lane] = 0;
   __syncthreads();
 #pragma unroll MPCQ_UNROLL_FACTOR
   for (int i = first; i >= 0; --i) {
@@ -1093,8 +1166,12 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
       vl_store(S + L.stv + VS, h, acc2);                         // rows 0..9: A^T p ; rows 10..13: B^T p
     }
     __syncthreads();
-    // ---- Lambda = R~ + F_uu, Cholesky in registers (redundantly on every lane, straight-line code);
-    //      lanes b<13: K[:,b] = -Lambda^-1 M[:,b] and p_i[b]; lanes 13..16: column of Lambda^-1 and k_i
+    // transposed T1'' elements of the position columns of P_i: read now, consumed by the P update behind the solve
+    TQ tT[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tT[s] = S[toff[s]];
+    // ---- Lambda = R~ + F_uu, LDL^T in registers (redundantly on every lane, straight-line code), then the solves
+    TQ kk, mop, pcol;
     {
       TQ Lm[4][4], mk[4];
 #pragma unroll
@@ -1140,18 +1217,19 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
         }
       }
       PF_FAC(13);                        // 4x4 LDL^T
-      // rhs: M[:,b] for lanes < 13 (b < 10: F''[10+j][b]; position b = 10+t: T1''[10+t][10+j]), e_j for lanes 13..16
-      TQ y[4], g[4];
+      // rhs: M[:,c] on the lanes of column c < 13, e_vj on the four Lambda^-1 lanes
+      TQ y[4], g[4], mvv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const TQ mv = S[m3off + j * m3str];
-        y[j] = mk[j] * (lane < NX ? mv : ((lane - NX) == j ? TQ(1) : TQ(0)));
+        mvv[j] = mv;
+        y[j] = mk[j] * (c < NX ? mv : ((inv && vj == j) ? TQ(1) : TQ(0)));
         const TQ gu = S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j];     // gt = rho + B^T p
         g[j] = mk[j] * gu;
         if (affine) gmax = tmax(gmax, tabs(g[j]));
         if (affine && mrows && mk[j] == TQ(0)) {   // what the multiplier of a pinned input j needs: [M_j | F_uu row j | gt_j]
-          if (lane < NX) mrows[(i * NU + j) * MROW + lane] = mv;
-          else if (lane - NX == j) {
+          if (h == 0 && c < NX) mrows[(i * NU + j) * MROW + c] = mv;
+          else if (inv && vj == j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) mrows[(i * NU + j) * MROW + NX + q] = S[L.sF + j * VS + 10 + q];
             mrows[(i * NU + j) * MROW + NX + 4] = gu;
@@ -1170,38 +1248,44 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 #pragma unroll
         for (int k = cc + 1; k < 4; ++k) y[cc] -= Lm[k][cc] * y[k];
       }
-      // lanes < 13 store K[:,b] = -y and p_i[b] = (A^T p)[b] - y.gt ; lanes 13..16 store Lambda^-1[vj][:] = y and k_vj = -y.gt
+      if (polish) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] *= mk[j];
+      }
+      // column lanes: K[:,c] = -y, p_i[c] = (A^T p)[c] - y.gt (+ q_i[c]); Lambda^-1 lanes: row vj = y, k_vj = -y.gt
       const TQ dot = y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3];
       const TQ tb = S[tboff];
-      if (lane < NY) {
-        TQ* o4 = S + (lane < NX ? L.K + i * KS + lane : L.Linv + i * 16 + vj * 4);
+      if (h == 0 && c < NX) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o4[j * o4str] = o4sgn * y[j] * (polish ? mk[j] : TQ(1));
-        TQ ex = tbm * tb - dot;
-        if (affine && lane < NX) ex += qvi;   // stage gradient q_i enters the recursion directly
-        if (polish && lane >= NX) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (vj == j) ex *= mk[j];
-        }
-        S[(lane < NX ? L.spv + lane : L.vin + i * VS + vj)] = ex;
+        for (int j = 0; j < 4; ++j) S[L.K + i * KS + j * ABW + c] = -y[j];
       }
+      if (inv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[L.Linv + i * 16 + vj * 4 + j] = y[j];
+        TQ kv = -dot;
+        if (polish) kv *= vj == 0 ? mk[0] : (vj == 1 ? mk[1] : (vj == 2 ? mk[2] : mk[3]));
+        S[L.vin + i * VS + vj] = kv;
+      }
+      TQ ex = tb - dot;
+      if (affine) ex += qvi;                // stage gradient q_i enters the recursion directly
+      pcol = c < NX ? ex : TQ(0);
+      const TQ yh = h == 0 ? y[0] : (h == 1 ? y[1] : (h == 2 ? y[2] : y[3]));
+      const TQ mh = h == 0 ? mvv[0] : (h == 1 ? mvv[1] : (h == 2 ? mvv[2] : mvv[3]));
+      kk = c < NX ? -yh : TQ(0);
+      mop = mmask * mh;
     }
-    PF_FAC(14);                          // right-hand sides, substitutions, stores of K, Lambda^-1, p
+    PF_FAC(14);                          // right-hand sides, substitutions, stores of K, Lambda^-1
     if (i == 0) break;
-    __syncthreads();
-    // ---- P_i = Q + G + M^T K as one k=4 tile on top of the assembled C operand
+    // ---- P_i = Q + G + M^T K as one k=4 tile on top of the assembled C operand; p_i back to column 14 through DPP
     {
-      const TQ mk = mmask * S[moff];
-      const TQ kk = S[L.K + i * KS + h * ABW + c];
       TQ C4[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        C4[s] = mA2[s] * acc2[s] + mA1[s] * acc1[s] + mPo[s] * Pop[s] + mT[s] * S[toff[s]] + qdg[s];
-      mfma(C4, mk, kk);
+        C4[s] = mA2[s] * acc2[s] + mA1[s] * acc1[s] + mPo[s] * Pop[s] + mT[s] * tT[s] + qdg[s];
+      mfma(C4, mop, kk);
 #pragma unroll
       for (int s = 0; s < 4; ++s) { Pop[s] = C4[s]; cur[s] = nxt[s]; }
-      vl_load(S + L.spv, h, pv);
+      l2g<TQ>(pcol, h, pv);
       if (pstore) {   // cost-to-go of this stage, for a later restart below it
 #pragma unroll
         for (int s = 0; s < 4; ++s) pstore[i * PST + lane * 4 + s] = Pop[s];
@@ -1211,7 +1295,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
         }
       }
     }
-    __syncthreads();
+    __syncthreads();   // the hand-over arrays are rewritten by the next stage
   }
   __syncthreads();
   if (affine && gscale) *gscale = gmax;   // every lane saw every stage gradient
@@ -1223,7 +1307,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L
 // vector sweeps.  Continues from the current (z, sl, su, ll, lu, dx, grad) until |r_d| <= tol*gm and
 // mu <= tol.  returns 0 converged / 1 NaN / 2 iteration cap / 4 stage Hessian not positive definite
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_COLD int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
+MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int status = 2;
   const int maxit = m.qp_max_iter;
@@ -1317,7 +1401,7 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, const T
 // that block are pinned.  Ends on an exact KKT point of the QP (to rounding), which an interior
 // method only approaches like sqrt(mu) on weakly active bounds.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
+MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
   why = QPX_BUDGET;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
@@ -1392,7 +1476,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
       pf.acc[13] += (keep_p && top >= 0 && top < N - 1) ? top + 1 : N;   // stages this factorisation visits
       pf.acc[14] += 1;                                                    // factorisations
 #endif
-      const bool fok = riccati_factor<C, true, true>(m, S, A, L PF_PASS, &gfac, nact > 0 ? G + L.mrow : nullptr, keep_p ? G + L.pst : nullptr, top);
+      const bool fok = riccati_factor<C, true, true>(m, S, A, L PF_PASS, &gfac, nact > 0 ? G + L.mrow : P<TQ>(nullptr), keep_p ? G + L.pst : P<TQ>(nullptr), top);
       top = -1;
       PF_STOP(PF_FACTOR);
       if (!fok) { why = QPX_NUMERIC; return false; }
@@ -1429,7 +1513,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
         TQ lam = 0;
         if (a != TQ(0)) {
           const int st = i >> 2, j = i & 3;
-          const TQ* row = G + L.mrow + i * MROW;
+          const P<TQ> row = G + (L.mrow + i * MROW);
           TQ rv[NX + 5];
 #pragma unroll
           for (int k = 0; k < NX + 5; ++k) rv[k] = row[k];
@@ -1537,7 +1621,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L,
 // rollout and a gradient sweep first): used for TQ = float, where increments keep their accuracy while a from-scratch
 // affine solve would have to be refined again every time.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
+MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
   why = QPX_BUDGET;
   bool fresh = false;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
@@ -1700,7 +1784,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, TQ* S, TQ* A, const Ld
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L, int* status, const int prev_iter PF_ARG) {
+MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const Lds& L, int* status, const int prev_iter PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0, why = 0;
   TQ gm = 1;
@@ -1776,20 +1860,21 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, TQ* S, TQ* A, TQ* G, const Lds& L
 //   J = k* Kx^-1 ; mu_p = J mu ; Cp = sf2 - J k* + J C J^T ; G = C J^T/(Cp + sn2) ;
 //   mu += G (y - mu_p) ; C -= G (J C)      (not symmetrised, as in the reference)
 template <typename C, typename TQ = typename C::T>
-MPCQ_PHASE void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu, TQ* gC, const double* vb, const double* ad, bool c_staged = false) {
+MPCQ_PHASE void rgp_regress(const DevModel<TQ>& m, P<TQ> S, const Lds& L, P<TQ> gmu, P<TQ> gC, P<const double> vb, P<const double> ad, bool c_staged = false) {
   const int n = cNB<C>(m), tid = lane_id(), NT = blockDim.x, n3 = 3 * n, nn = n * n;
-  TQ* Cw = S + L.rgp;
-  TQ* ks = Cw + al4(3 * nn);
-  TQ* Jt = ks + al4(n3);
-  TQ* JC = Jt + al4(n3);
-  TQ* CJ = JC + al4(n3);
-  TQ* mu = CJ + al4(n3);
-  TQ* sc = mu + al4(n3);
+  const P<TQ> Cw = S + L.rgp;
+  const P<TQ> ks = Cw + al4(3 * nn);
+  const P<TQ> Jt = ks + al4(n3);
+  const P<TQ> JC = Jt + al4(n3);
+  const P<TQ> CJ = JC + al4(n3);
+  const P<TQ> mu = CJ + al4(n3);
+  const P<TQ> sc = mu + al4(n3);
+  const P<const TQ> Kxinv = mk(m.Kxinv, 3L * nn, CK_KXINV), basis = mk(m.basis, n3, CK_BASIS);
   if (!c_staged)
     for (int i = tid; i < 3 * nn; i += NT) Cw[i] = gC[i];
   for (int i = tid; i < n3; i += NT) {
     const int d = i / n;
-    const TQ dl = (TQ)vb[d] - m.basis[i];
+    const TQ dl = (TQ)vb[d] - basis[i];
     ks[i] = m.sf2[d] * texp(TQ(-0.5) * dl * dl * m.L2inv[d]);
     mu[i] = gmu[i];
   }
@@ -1797,7 +1882,7 @@ MPCQ_PHASE void rgp_regress(const DevModel<TQ>& m, TQ* S, const Lds& L, TQ* gmu,
   for (int i = tid; i < n3; i += NT) {
     const int d = i / n, j = i % n;
     TQ t = 0;
-    for (int k = 0; k < n; ++k) t += ks[d * n + k] * m.Kxinv[d * nn + k * n + j];
+    for (int k = 0; k < n; ++k) t += ks[d * n + k] * Kxinv[d * nn + k * n + j];
     Jt[i] = t;
   }
   __syncthreads();
@@ -1846,11 +1931,15 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
   const int b = blockIdx.x;
   const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
-  double* D = reinterpret_cast<double*>(smem_raw);
-  TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
-  TQ* G = st.stage + (size_t)b * L.gtotal;   // per-instance record in global memory
-  TQ* A = S;   // base of the stage records
-  if (GAB) A = G;
+#ifdef MPCQ_CHECKED
+  if (tid == 0) *reinterpret_cast<int**>(smem_raw) = st.chk;   // where violations are recorded (ck_rec)
+  if (tid == 0 && b == 0 && st.chk) { const unsigned long long pc = __builtin_amdgcn_s_getpc(); st.chk[9] = (int)(unsigned)pc; st.chk[10] = (int)(unsigned)(pc >> 32); }
+  __syncthreads();
+#endif
+  const P<double> D = mk(reinterpret_cast<double*>(smem_raw + CK_HDR), L.dbytes / 8, CK_LDS_D);
+  const P<TQ> S = mk(reinterpret_cast<TQ*>(smem_raw + CK_HDR + L.dbytes), L.qtotal, CK_LDS_Q);
+  const P<TQ> G = mk(st.stage + (size_t)b * L.gtotal, L.gtotal, CK_STAGE);   // per-instance record in global memory
+  const P<TQ> A = GAB ? G : S;   // base of the stage records
   const bool gp = nb > 0;
 #ifdef MPCQ_PROFILE
   Prof pf;
@@ -1864,24 +1953,26 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   for (int period = 0; period < periods; ++period) {
   // ---- load persistent state (lane-contiguous records) and form the QP data in double.  All global
   //      loads of a block are issued before the first use so their latencies overlap.
-  double* gX = st.X + (size_t)b * (N + 1) * NX;
-  double* gU = st.U + (size_t)b * N * NU;
+  const P<double> gX = mk(st.X + (size_t)b * (N + 1) * NX, (N + 1) * NX, CK_X);
+  const P<double> gU = mk(st.U + (size_t)b * N * NU, N * NU, CK_U);
   const int idx = st.idx[b];
   int have = 0, len = 1;
-  const double* tr = nullptr;
+  P<const double> tr = nullptr;
   if (mode & MODE_TRAJ) {
     len = st.tlen[b];
     have = chunk_have(len, idx, N, m.skip);
-    tr = st.traj + (size_t)b * m.Tmax * NX;
+    tr = mk(st.traj + (size_t)b * m.Tmax * NX, (long)m.Tmax * NX, CK_TRAJ);
   }
-  const double* gy = st.yref + (size_t)b * N * NY;
-  const double* gyN = st.yrefN + (size_t)b * NX;
+  const P<const double> gy = mk((const double*)st.yref + (size_t)b * N * NY, N * NY, CK_YREF);
+  const P<const double> gyN = mk((const double*)st.yrefN + (size_t)b * NX, NX, CK_YREFN);
   auto xref = [&](int i, int k) -> double {  // reference of node i (i == N: terminal = chunk row N-1)
     if (mode & MODE_TRAJ) return tr[chunk_row(i < N ? i : N - 1, have, idx, m.skip, len) * NX + k];
     return i < N ? gy[i * NY + k] : gyN[k];
   };
   auto uref = [&](int i, int k) -> double { return (mode & MODE_TRAJ) ? m.uref[k] : gy[i * NY + NX + k]; };
-  TQ* gmu = st.mu + (size_t)b * 3 * nb;
+  const P<TQ> gmu = mk(st.mu + (size_t)b * 3 * nb, 3 * nb, CK_MU);
+  const P<double> gW = mk(st.w + (size_t)b * NU, NU, CK_W), gRunX = mk(st.run_x ? st.run_x + (size_t)b * NX : nullptr, NX, CK_RUNX);
+  const P<const TQ> mKxinv = mk(m.Kxinv, 3L * nb * nb, CK_KXINV), mBasis = mk(m.basis, 3 * nb, CK_BASIS);
   // Every independent global load of the phase is issued before the first use, so the phase costs about one
   // memory round trip (plus the cursor, which the reference rows depend on).
   constexpr int UNR = 5;
@@ -1900,18 +1991,18 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     if (tid == 0) {
       double x[NX], u[NU];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) x[k] = st.run_x[(size_t)b * NX + k];
+      for (int k = 0; k < NX; ++k) x[k] = gRunX[k];
 #pragma unroll
-      for (int k = 0; k < NU; ++k) u[k] = st.w[(size_t)b * NU + k];
+      for (int k = 0; k < NU; ++k) u[k] = gW[k];
       for (int sub = 0; sub < st.run_nsub; ++sub) plant_rk4(m, x, u, st.run_dt);
 #pragma unroll
-      for (int k = 0; k < NX; ++k) { st.run_x[(size_t)b * NX + k] = x[k]; D[L.x0 + k] = x[k]; }   // the new plant state IS this period's measurement
+      for (int k = 0; k < NX; ++k) { gRunX[k] = x[k]; D[L.x0 + k] = x[k]; }   // the new plant state IS this period's measurement
     }
   }
   const bool meas_from_plant = (mode & MODE_PLANT_FIRST) != 0;   // then lane 0 has already put it into LDS (no store -> load hand-over through memory)
-  const double xm = (tid < NX && !meas_from_plant) ? st.x_meas[(size_t)b * NX + tid] : 0.0;
+  const double xm = (tid < NX && !meas_from_plant) ? mk(st.x_meas + (size_t)b * NX, NX, CK_XMEAS)[tid] : 0.0;
   if (gp) {   // mu -> LDS scratch (shooting records are not live yet); rows of Kx^-1 come straight from L2
-    for (int i = tid; i < 3 * nb; i += 64) { S[L.sub + i] = gmu[i]; S[L.basis + i] = m.basis[i]; }
+    for (int i = tid; i < 3 * nb; i += 64) { S[L.sub + i] = gmu[i]; S[L.basis + i] = mBasis[i]; }
   }
   // U -> LDS, r0 = R (U_i - uref_i), bounds
   for (int it = tid; it < nv; it += 64) {
@@ -1948,8 +2039,8 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     // alpha = Kx^-1 mu  (the OCP model evaluates k*(v_b) Kx^-1 p, src/gp/RGP.py:250-254)
     for (int i = tid; i < 3 * nb; i += 64) {
       const int d = i / nb, r = i - d * nb;
-      const TQ* kr = m.Kxinv + d * nb * nb + r * nb;
-      const TQ* mu = S + L.sub + d * nb;
+      const P<const TQ> kr = mKxinv + (d * nb * nb + r * nb);
+      const P<TQ> mu = S + (L.sub + d * nb);
       TQ t = 0;
       int k = 0;
       for (; k + 5 <= nb; k += 5) {
@@ -1976,7 +2067,8 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   __syncthreads();
   // ---- 2. QP
   int status = 0;
-  const int iters = solve_qp<C>(m, S, A, G, L, &status, st.qp_iter[b] PF_PASS);
+  const int prev_iter = st.qp_iter[b];
+  const int iters = solve_qp<C>(m, S, A, G, L, &status, prev_iter PF_PASS);
   PF_START();
   // ---- 3. full step (iterate accumulated in double).  A step that is not finite (a QP that broke down: only seen
   //      with the fp32 QP on infeasible references) is not taken: the iterate and the control of the previous period
@@ -2031,21 +2123,22 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   if (bad) status = 1;
   // TQ = float: a step whose QP went through the interior-point fallback is outside the 1e-4 control budget of the fast mode
   // (include/mpcq.h, MPCQ_SOLVE_LOW_ACCURACY): taken, but reported
-  if (sizeof(TQ) == 4 && status == 0 && (iters / 1000) % 10 != 0) status = 8;
+  if (sizeof(TQ) == 4 && status == 0 && ((iters / 1000) % 10 != 0 || prev_iter == 0)) status = 8;   // fallback solve or cold start
   if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; }
   if (tid < NU) {
-    st.w[(size_t)b * NU + tid] = D[L.U + tid];
+    gW[tid] = D[L.U + tid];
     if (st.w_ext) st.w_ext[(size_t)b * NU + tid] = D[L.U + tid];
   }
   PF_STOP(PF_ELEM);
   PF_START();
   if (mode & MODE_POST) {
   // ---- 4. post: nominal prediction, cursor, drag estimate, RGP regress, statistics
-  double* vbad = D + L.x0 + NX;   // [v_body(3), a_drag(3)]
+  const P<double> vbad = D + (L.x0 + NX);   // [v_body(3), a_drag(3)]
+  const P<TQ> gCov = mk(st.C + (size_t)b * 3 * nb * nb, 3L * nb * nb, CK_C);
+  const P<double> gXpp = mk(st.xpp + (size_t)b * NX, NX, CK_XPP), gXpred = mk(st.xpred + (size_t)b * NX, NX, CK_XPRED);
   const bool regress = gp && !(mode & MODE_STATIC_GP);
   if (regress) {   // stage the covariance while lane 0 integrates the nominal model (QP workspace is dead)
-    const TQ* gC = st.C + (size_t)b * 3 * nb * nb;
-    for (int i = tid; i < 3 * nb * nb; i += 64) S[L.rgp + i] = gC[i];
+    for (int i = tid; i < 3 * nb * nb; i += 64) S[L.rgp + i] = gCov[i];
   }
   if (tid == 0) {
     double x[NX], u[NU], xp[NX];
@@ -2058,7 +2151,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     double xq[NX];
     const bool hp = st.has_prev[b] != 0;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) xq[k] = hp ? st.xpp[(size_t)b * NX + k] : x[k];
+    for (int k = 0; k < NX; ++k) xq[k] = hp ? gXpp[k] : x[k];
     double R[9], Rq[9];
     rotmat(x + 3, R);
     rotmat(xq + 3, Rq);
@@ -2070,7 +2163,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
       vbad[3 + i] = (vb - vp) / m.dt_pred;
     }
 #pragma unroll
-    for (int k = 0; k < NX; ++k) { st.xpred[(size_t)b * NX + k] = xp[k]; st.xpp[(size_t)b * NX + k] = xp[k]; }
+    for (int k = 0; k < NX; ++k) { gXpred[k] = xp[k]; gXpp[k] = xp[k]; }
     st.has_prev[b] = 1;
     st.idx[b] = idx + 1;
     // tracking statistic against the first row of the reference chunk
@@ -2080,25 +2173,25 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
       const double a = x[k] - xref(0, k), c = x[7 + k] - xref(0, 7 + k);
       ep += a * a; ev += c * c;
     }
-    double* gs = st.stats + (size_t)b * 4;
+    const P<double> gs = mk(st.stats + (size_t)b * 4, 4, CK_STATS);
     gs[0] += ep; gs[1] += ev; gs[2] += 1; gs[3] = tmax(gs[3], ep);
     // trajectory finished (src/mpc_controller_node.py:374, evaluated after idx_traj += 1): the cursor stands on the last
     // row and the quadrotor is within EPSILON_TRAJECTORY_FINISHED of the first row of this step's chunk
     if ((mode & MODE_TRAJ) && idx + 2 == len && sqrt(ep) < m.finish_r) st.finished[b] = 1;
   }
   __syncthreads();
-  if (regress) rgp_regress<C>(m, S, L, gmu, st.C + (size_t)b * 3 * nb * nb, vbad, vbad + 3, true);
+  if (regress) rgp_regress<C>(m, S, L, gmu, gCov, vbad, vbad + 3, true);
   }
   if (C::RUN) {   // the plant produces the next measurement (plant_kernel of the lockstep path)
     if (tid == 0) {
       double x[NX], u[NU];
 #pragma unroll
-      for (int k = 0; k < NX; ++k) x[k] = st.run_x[(size_t)b * NX + k];
+      for (int k = 0; k < NX; ++k) x[k] = gRunX[k];
 #pragma unroll
       for (int k = 0; k < NU; ++k) u[k] = D[L.U + k];
       for (int sub = 0; sub < st.run_nsub; ++sub) plant_rk4(m, x, u, st.run_dt);
 #pragma unroll
-      for (int k = 0; k < NX; ++k) st.run_x[(size_t)b * NX + k] = x[k];
+      for (int k = 0; k < NX; ++k) gRunX[k] = x[k];
     }
   }
   __syncthreads();
@@ -2129,9 +2222,14 @@ __global__ void predict_kernel(const DevModel<TQ> m, const double* x, const doub
 template <typename TQ>
 __global__ void regress_kernel(const DevModel<TQ> m, const DevState<TQ> st, const double* vb, const double* ad) {
   const Lds L = lds_layout(m.N, m.nb, m.gab);
-  TQ* S = reinterpret_cast<TQ*>(smem_raw + L.dbytes);
-  const int b = blockIdx.x;
-  rgp_regress<Cfg<TQ, false>>(m, S, L, st.mu + (size_t)b * 3 * m.nb, st.C + (size_t)b * 3 * m.nb * m.nb, vb + (size_t)b * 3, ad + (size_t)b * 3);
+#ifdef MPCQ_CHECKED
+  if (threadIdx.x == 0) *reinterpret_cast<int**>(smem_raw) = st.chk;
+  __syncthreads();
+#endif
+  const P<TQ> S = mk(reinterpret_cast<TQ*>(smem_raw + CK_HDR + L.dbytes), L.qtotal, CK_LDS_Q);
+  const int b = blockIdx.x, nb = m.nb;
+  rgp_regress<Cfg<TQ, false>>(m, S, L, mk(st.mu + (size_t)b * 3 * nb, 3 * nb, CK_MU), mk(st.C + (size_t)b * 3 * nb * nb, 3L * nb * nb, CK_C),
+                              mk(vb + (size_t)b * 3, 3, CK_XMEAS), mk(ad + (size_t)b * 3, 3, CK_XMEAS));
 }
 
 // closed-loop plant: n_sub RK4 substeps of the drag plant from the engine's plant state with input w

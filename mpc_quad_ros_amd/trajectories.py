@@ -189,25 +189,44 @@ def minsnap_mission(seed: int, index: int, min_samples: int, v_max: float = 12.0
     return np.concatenate(rows)
 
 
-def _mission_job(args):
-    return minsnap_mission(*args[0], **args[1])
+def _mission_chunk(args):
+    """Worker: missions of a contiguous index block, as float32-free compact rows (positions and velocities; the other
+    columns of a reference are constants)."""
+    seed, first, count, min_samples, kw = args
+    return [np.ascontiguousarray(minsnap_mission(seed, first + i, min_samples, **kw)[:, [0, 1, 2, 7, 8, 9]]) for i in range(count)]
 
 
-def swarm_missions(seed: int, first_index: int, count: int, min_samples: int, **kw):
-    """Padded batch of missions (see minsnap_mission): (traj [count, Tmax, 13], lengths [count]); generated by a pool of host threads."""
-    jobs = [((seed, first_index + i, min_samples), kw) for i in range(count)]
-    if count >= 64:      # threads, not processes: the solver and the sampler are C++ calls that release the GIL
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as pool:
-            trajs = list(pool.map(_mission_job, jobs))
+def swarm_missions(seed: int, first_index: int, count: int, min_samples: int, workers=None, max_rows=None, **kw):
+    """Padded batch of missions (see minsnap_mission): (traj [count, Tmax, 13], lengths [count]).  Large batches are
+    generated by forked worker processes (one contiguous index block each; a mission depends only on (seed, index), so the
+    result does not depend on the partition): call this BEFORE the process touches the GPU.
+    max_rows: keep only the first max_rows rows of every mission (a run of K periods at horizon N with chunk stride `skip`
+    reads rows < K + N skip; the rest of the last flight only costs host memory)."""
+    import os
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+        workers = max(1, min(workers, 16, count // 64))
+    if workers > 1:
+        import multiprocessing as mp
+        block = (count + 4 * workers - 1) // (4 * workers)
+        jobs = [(seed, first_index + lo, min(block, count - lo), min_samples, kw) for lo in range(0, count, block)]
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_mission_chunk, jobs)
+        trajs = [t for part in parts for t in part]
     else:
-        trajs = [_mission_job(j) for j in jobs]
+        trajs = _mission_chunk((seed, first_index, count, min_samples, kw))
+    if max_rows is not None:
+        trajs = [t[:max_rows] for t in trajs]
     lens = np.array([t.shape[0] for t in trajs], dtype=np.int32)
     out = np.zeros((count, int(lens.max()), NX))
+    out[:, :, 3] = 1.0
     for i, t in enumerate(trajs):
-        out[i, :t.shape[0]] = t
-        out[i, t.shape[0]:] = t[-1]
+        n = t.shape[0]
+        out[i, :n, 0:3] = t[:, 0:3]; out[i, :n, 7:10] = t[:, 3:6]
+        out[i, n:, 0:3] = t[-1, 0:3]; out[i, n:, 7:10] = t[-1, 3:6]
     return out, lens
 
 

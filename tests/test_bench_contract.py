@@ -34,7 +34,11 @@ def test_single_rank_line():
                                    "--batch", "2", "--horizon", "5", "--nb", "10", "--no-cpu-baseline", "--no-alt"], cwd=ROOT)
     lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1
-    _check(lines[0], 1)
+    d = _check(lines[0], 1)
+    # the oracle-parity leg of the line (here: emulated lanes vs the oracle on the tiny workload)
+    p = d["parity_on_workload"]
+    assert p["quad_steps"] == 2 * 30 and p["max_rel_dev"] < 1e-7 and p["failed"] == 0
+    assert d["roofline"]["traffic"] is None and "no PMC profile" in d["roofline"]["traffic_note"]
 
 
 def test_two_ranks_under_torchrun():

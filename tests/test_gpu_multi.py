@@ -140,6 +140,9 @@ def test_step_device_async_matches_host_step(precision):
     assert np.array_equal(tail, guard)              # nothing written past [B,4] doubles
     for k, v in a.get_state().items():
         assert np.array_equal(v, b.get_state()[k]), k
+    # the engine's own control record follows a step with a caller-supplied control buffer: command mapping and plant agree
+    for ca, cb in zip(a.get_command(), b.get_command()):
+        assert np.array_equal(ca, cb)
     hip.free(dx); hip.free(dw)
 
 

@@ -63,12 +63,15 @@ def test_swarm_closed_loop_config2_shape():
 
 
 def test_long_horizon_config5_shape():
-    # BASELINE configs[4] shape N=50 / nb=50 in f32 (the whole working set fits the LDS of a CU): 64 quadrotors x 60
-    # periods from hover.  (Started 2 s into the references with a cold iterate -- the protocol of the fp64 test below --
-    # three of the 64 quadrotors spend their first periods with three rotors saturated at zero thrust and interior-point
-    # solves every step: there the f32 QP is 1e-2..7e-2 off, the regime DESIGN.md section 5 excludes for the fast mode.)
+    # BASELINE configs[4] shape N=50 / nb=50 in f32 (experimental mode), same protocol as the fp64 test below: started 2 s into
+    # the references with a cold iterate.  Some quadrotors spend their first periods with rotors saturated and interior-point
+    # solves every step: the f32 QP is 1e-2..7e-2 off there and the engine SAYS so (MPCQ_SOLVE_LOW_ACCURACY); every instance
+    # solve it does not flag holds the 1e-4 budget (teacher-forced: every solve judged on its own).
+    worst = pc.case_swarm_closed_loop(make, B=64, N=50, nb=50, K=60, precision=1, start=200, flagged_bound=0.5)
+    print("config-5 shape, f32, cold start in flight: worst relative control deviation of the unflagged solves", worst)
+    assert worst < 1e-3       # OUTSIDE the 1e-4 budget (observed 2.1e-4): the experimental mode is not for this regime
     worst = pc.case_swarm_closed_loop(make, B=64, N=50, nb=50, K=60, precision=1)
-    print("config-5 shape, f32: worst relative control deviation", worst)
+    print("config-5 shape, f32, from hover: worst relative control deviation", worst)
     assert worst < 1e-4
 
 
@@ -114,7 +117,7 @@ def test_kernel_variants_agree(precision, shape):
             ws = []
             for k in range(K):
                 e.sim_steps(1, 2, 5e-3)
-                assert (e.get_status() == 0).all()
+                assert ((e.get_status() & 7) == 0).all()
                 ws.append(e.sim_get_state()[1].copy())
             out[(mem, generic)] = np.array(ws)
             e.close()
@@ -132,8 +135,8 @@ def test_kernel_variants_agree(precision, shape):
     ("log_trajectory_v15_a5_gp2.npz", 80), ("log_traj2_v10_a10_gp2.npz", 100), ("log_traj1_v15_a5_gp2.npz", 45)])
 def test_f32_qp_mode_teacher_forced(name, K):
     """Fast mode (QP arithmetic in float, state / QP data in double) on the same six logs and windows as the fp64 test:
-    tolerance 1e-4 relative control deviation (the north_star budget) on every warm-started solve; interior-point fallback
-    solves may exceed it within parity_cases.F32_LOG_BUDGET (three logs, reported)."""
+    tolerance 1e-4 relative control deviation (the north_star budget) on every solve the engine reports with status 0; solves
+    it flags MPCQ_SOLVE_LOW_ACCURACY (interior point in float) are held to parity_cases.F32_FLAGGED_BOUND and printed."""
     worst = pc.case_teacher_forced_log(make, name, K, precision=1, check_rgp=False)
     print(name, "f32 worst relative control deviation", worst)
 
@@ -207,7 +210,7 @@ def test_whole_trajectories_full_batch(precision):
         e.sim_reset(x0)
         getattr(e, mode)(900, 2, 5e-3)
         st = e.get_tracking_stats()
-        assert (e.get_status() == 0).all()
+        assert ((e.get_status() & 7) == 0).all()
         assert st[2] == 900 * B and st[4] == 0
         assert np.sqrt(st[0] / (3 * st[2])) < 0.05 and np.sqrt(st[3]) < 1.0     # rms / worst position error [m]
         out.append((e.sim_get_state(), e.get_state()["X"], st))
@@ -240,6 +243,59 @@ def test_missions_soak_full_batch():
     assert out[0][3] > 20                       # interior-point fallbacks seen at the sampled periods alone
     assert np.array_equal(out[0][0][0], out[1][0][0]) and np.array_equal(out[0][0][1], out[1][0][1])
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_bench_workload_parity_vs_oracle():
+    """Oracle parity ON THE WORKLOAD THE HEADLINE IS MEASURED ON: the bench engine (1 024 quadrotors in continuous operation on
+    min-snap missions at v_max = a_max = 12) is pre-rolled 600 periods on the device and dumped; 64 quadrotors -- every one
+    whose last solve went through the interior point, filled up from the low indices -- are then continued host-driven for 120
+    periods next to the fp64 oracle, teacher-forced (1e-7 on the controls, 1e-10 on the RGP posterior) and free-running
+    (1e-6 on every quadrotor whose iteration is contractive over the window, as measured by a perturbed twin of the oracle).  The window must exercise what the solver heuristics were tuned on: interior-point fallbacks, flip-marked solves
+    and the early exits of the warm attempt (src/mpc_controller_node.py:278-318 on both sides)."""
+    import bench
+    B, pre, K = 1024, 600, 120
+    refs = bench.workload(2026, 0, B, pre + K)
+    e, _ = bench.make_engine(B, 20, 10, 0, 0, 0, 2026, refs=refs)
+    e.sim_run(pre, 2, 5e-3)
+    assert (e.get_status() == 0).all()
+    dump = bench.dump_engine(e)
+    e.close()
+    r = bench.parity_on_workload(dump, refs, 20, 10, 0, quads=64, periods=K, free_running=True)
+    print("bench workload vs oracle:", r)
+    assert r["failed"] == 0
+    assert r["max_rel_dev"] < 1e-7 and r["max_rel_dev_per_quad"] < 1e-7, r
+    assert r["rgp_max_rel_dev"] < 1e-10, r
+    # free-running: every quadrotor on which the RTI iteration is contractive over the window (the oracle's own 1e-10 twin stays
+    # within 1e-7) holds 1e-6; the sensitive ones (saturated, decimetres off their reference) amplify any difference -- there the
+    # engine may not drift further from the oracle than 1e4 x what the oracle's twin does (its rounding differences are ~1e-12, the
+    # twin's perturbation 1e-10)
+    assert r["free_running_max_rel_dev"] < 1e-6 and r["free_running_contractive_quads"] >= 48, r
+    assert r["free_running_sensitive_quads"]["engine_over_twin_worst_ratio"] < 1e4, r
+    assert r["fallbacks"] >= 50 and r["flip_marked"] >= 10 and r["warm_exit_pins"] + r["warm_exit_wrong"] >= 1, r
+
+
+def test_config4_full_size():
+    """BASELINE configs[4] at full size (4 096 quadrotors, N = 50, 50 RGP basis points per axis, fp64 with the stage records in
+    global memory): both launch modes agree bit for bit, every instance solves, controls respect the box."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N, nb, K = 4096, 50, 50, 30
+    traj, lens = swarm_trajectories(9, 0, B)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    out = []
+    for mode in ("sim_steps", "sim_run"):
+        e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb)))
+        e.set_trajectories(traj, lens)
+        e.sim_reset(x0)
+        getattr(e, mode)(K, 2, 5e-3)
+        assert (e.get_status() == 0).all()
+        x, w = e.sim_get_state()
+        assert w.min() >= 0.0 and w.max() <= 1.0 and np.isfinite(x).all()
+        st = e.get_tracking_stats()
+        assert st[2] == K * B and st[4] == 0 and np.sqrt(st[3]) < 1.0
+        out.append((x, w, st))
+        e.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
 def test_config2_full_size():

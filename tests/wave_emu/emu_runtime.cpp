@@ -1,6 +1,7 @@
 // tests/wave_emu/emu_runtime.cpp — fiber scheduler + host-runtime stubs of the TEST-ONLY emulator.
 #include <ucontext.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <cstdio>
@@ -21,7 +22,7 @@ std::vector<Fiber> fibers;
 ucontext_t sched_ctx;
 const std::function<void()>* body_ptr = nullptr;
 int current = -1;
-std::vector<uint64_t> exch(1024), exch2(1024);
+std::vector<uint64_t> exch(1024), exch2(1024), exch3(1024);
 void trampoline() {
   (*body_ptr)();
   fibers[current].done = true;
@@ -30,16 +31,21 @@ void trampoline() {
 }  // namespace
 uint64_t* exchange() { return exch.data(); }
 uint64_t* exchange2() { return exch2.data(); }
+uint64_t* exchange3() { return exch3.data(); }
 void sync() { swapcontext(&fibers[current].ctx, &sched_ctx); }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
   static const bool reverse = getenv("MPCQ_EMU_REVERSE") != nullptr;
+  static const char* shuffle = getenv("MPCQ_EMU_SHUFFLE");   // seed: lanes are resumed in a pseudo-random order that changes at every rendezvous
+  static uint64_t rng = shuffle ? (uint64_t)atoll(shuffle) * 0x9E3779B97F4A7C15ull + 1 : 0;
+  std::vector<int> order(block.x);
   const int nt = block.x;
   if (shmem > sizeof(mpcq::smem_raw)) { fprintf(stderr, "emu: shared memory request too large\n"); abort(); }
   fibers.resize(nt);
   body_ptr = &body;
   static const bool poison = getenv("MPCQ_EMU_POISON") != nullptr;
   for (unsigned b = 0; b < grid.x; ++b) {
+    std::fill(exch3.begin(), exch3.end(), 0);   // per-lane counts of EXEC reads (checked build)
     if (poison) std::memset(mpcq::smem_raw, 0xFF, sizeof(mpcq::smem_raw));   // LDS is not initialised on the device either: all-ones = NaN
     for (int t = 0; t < nt; ++t) {
       Fiber& f = fibers[t];
@@ -56,8 +62,14 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
     bool live = true;
     while (live) {
       live = false;
+      for (int k = 0; k < nt; ++k) order[k] = reverse ? nt - 1 - k : k;
+      if (shuffle)
+        for (int k = nt - 1; k > 0; --k) {   // Fisher-Yates with xorshift64
+          rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+          std::swap(order[k], order[(int)(rng % (uint64_t)(k + 1))]);
+        }
       for (int k = 0; k < nt; ++k) {
-        const int t = reverse ? nt - 1 - k : k;
+        const int t = order[k];
         if (fibers[t].done) continue;
         current = t;
         cur = &fibers[t].lane;

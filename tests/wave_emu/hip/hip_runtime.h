@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -69,12 +70,37 @@ inline int __double2loint(double d) { uint64_t u; std::memcpy(&u, &d, 8); return
 inline int __double2hiint(double d) { uint64_t u; std::memcpy(&u, &d, 8); return (int)(uint32_t)(u >> 32); }
 inline double __hiloint2double(int hi, int lo) { uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; std::memcpy(&d, &u, 8); return d; }
 inline unsigned long long __builtin_readcyclecounter_emu() { return 0; }
+// EXEC participation: every emulated cross-lane operation counts itself per lane (emu::arrive) and, behind its rendezvous,
+// lane 0 of the wave verifies that all 64 lanes have executed the same number of them -- a lane that skipped one under
+// divergent control flow (the thing a partial EXEC mask is on the device) is behind, and the run aborts naming the operation.
+// The checked build's own EXEC test (ck_exec in mpcq_kernels.hpp) therefore always sees a full mask here; it does its work on
+// the GPU.
+namespace emu { uint64_t* exchange3(); }
+namespace emu {
+inline void arrive() { exchange3()[cur->tid.x] += 1; }
+inline void verify(const char* what) {
+  const unsigned t = cur->tid.x;
+  if ((t & 63u) != 0) return;
+  const uint64_t* c = exchange3();
+  for (unsigned l = 1; l < 64 && l < cur->bdim.x; ++l)
+    if (c[(t & ~63u) | l] != c[t]) {
+      std::fprintf(stderr, "emu: %s executed under divergent control flow: lane %u has taken part in %llu cross-lane operations, lane 0 in %llu (workgroup %u)\n",
+                   what, l, (unsigned long long)c[(t & ~63u) | l], (unsigned long long)c[t], cur->bid.x);
+      std::abort();
+    }
+}
+}  // namespace emu
+inline unsigned long long __builtin_amdgcn_s_getpc() { return 0; }
+inline int atomicCAS(int* p, int cmp, int v) { const int old = *p; if (old == cmp) *p = v; return old; }
+inline unsigned long long __builtin_amdgcn_read_exec() { return ~0ull; }
 // v_readlane_b32: every lane receives lane `src`'s value (src wave-uniform)
 inline int __builtin_amdgcn_readlane(int v, int src) {
   uint64_t* ex = emu::exchange();
   const unsigned t = emu::cur->tid.x;
   ex[t] = (uint32_t)v;
+  emu::arrive();
   emu::sync();
+  emu::verify("v_readlane");
   const int r = (int)(uint32_t)ex[(t & ~63u) | ((unsigned)src & 63u)];
   emu::sync();
   return r;
@@ -91,7 +117,9 @@ inline V4 emu_mfma(T a, T b, V4 c) {
   std::memcpy(&ra, &a, sizeof(T));
   std::memcpy(&rb, &b, sizeof(T));
   ea[t] = ra; eb[t] = rb;
+  emu::arrive();
   emu::sync();
+  emu::verify("v_mfma");
   for (int reg = 0; reg < 4; ++reg) {
     const unsigned row = F64 ? h + 4 * reg : 4 * h + reg;
     T acc = c[reg];
@@ -116,7 +144,9 @@ inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool)
   uint64_t* ex = emu::exchange();
   const unsigned t = emu::cur->tid.x;
   ex[t] = (uint32_t)v;
+  emu::arrive();
   emu::sync();
+  emu::verify("DPP");
   unsigned src;
   if (ctrl <= 0xFF) src = (t & ~3u) | ((unsigned)(ctrl >> (2 * (t & 3))) & 3u);
   else if (ctrl >= 0x121 && ctrl <= 0x12F) src = (t & ~15u) | ((t - (unsigned)(ctrl - 0x120)) & 15u);
@@ -133,7 +163,9 @@ inline emu_u2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, boo
   uint64_t* eb = emu::exchange2();
   const unsigned t = emu::cur->tid.x, w = t & ~63u, l = t & 63u;
   ea[t] = a; eb[t] = b;
+  emu::arrive();
   emu::sync();
+  emu::verify("v_permlane32_swap");
   emu_u2 r;
   r[0] = l < 32 ? a : (unsigned)eb[w + l - 32];
   r[1] = l < 32 ? (unsigned)ea[w + l + 32] : b;
@@ -146,7 +178,9 @@ inline emu_u2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, boo
   uint64_t* eb = emu::exchange2();
   const unsigned t = emu::cur->tid.x, w = t & ~63u, l = t & 63u;
   ea[t] = a; eb[t] = b;
+  emu::arrive();
   emu::sync();
+  emu::verify("v_permlane16_swap");
   emu_u2 r;
   r[0] = (l & 16) ? (unsigned)eb[w + l - 16] : a;
   r[1] = (l & 16) ? b : (unsigned)ea[w + l + 16];

@@ -25,8 +25,9 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     lib = os.path.join(ROOT, "mpc_quad_ros_amd", "libmpcq_prof.so")
     import bench
-    e, _ = bench.make_engine(B, N, nb, prec, 0, 0, 2026, lib_path=lib)      # the bench workload (min-snap references)
-    e.sim_steps(int(os.environ.get('PREROLL', bench.PREROLL)), 2, 5e-3)   # same regime as bench.py
+    refs = bench.workload(2026, 0, B, int(os.environ.get('PREROLL', bench.PREROLL)) + steps)
+    e, _ = bench.make_engine(B, N, nb, prec, 0, 0, 2026, lib_path=lib, refs=refs)      # the bench workload (min-snap references)
+    e.sim_run(int(os.environ.get('PREROLL', bench.PREROLL)), 2, 5e-3)   # same regime as bench.py
     acc = np.zeros((B, 16))
     mx = np.zeros(16)
     its = []
@@ -38,7 +39,7 @@ def main():
         acc += out
         worst = out[:, 10].argmax()
         mx += out[worst]
-        its.append(e.get_qp_iter())
+        its.append(e.get_qp_iter() % 10000)
     its = np.array(its)
     mean = acc.mean(axis=0) / steps
     mxs = mx / steps
