@@ -189,8 +189,8 @@ def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps):
 
 
 def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None, periods=1000, refs=None):
-    """refs: (traj, lens) generated earlier -- the generator forks worker processes, which is done BEFORE this process
-    touches the GPU."""
+    """refs: (traj, lens) generated earlier (bench.workload forks worker processes: call it BEFORE this process touches the
+    GPU and pass the result here)."""
     traj, lens = refs if refs is not None else workload(seed, first_index, B, periods)
     cfg = EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb),
                        theta=[1.0, 0.1, 0.1], dt_pred=0.01, device=device, precision=precision)

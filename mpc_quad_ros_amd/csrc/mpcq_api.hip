@@ -18,7 +18,7 @@
 
 namespace mpcq {   // mpcq_spec.hip, one translation unit per specialised shape
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
-#ifdef MPCQ_CHECKED   // the checked build compiles for tens of minutes per specialised shape: only the headline shape has one there
+#if defined(MPCQ_CHECKED) || defined(MPCQ_ONE_SHAPE)   // the checked build compiles for tens of minutes per specialised shape: only the headline shape has one there (MPCQ_ONE_SHAPE: quick A/B variants, `make variant SHAPES=20_10 EXTRA=-DMPCQ_ONE_SHAPE`)
 #define MPCQ_SPEC_SHAPES(X) X(20, 10)
 #else
 #define MPCQ_SPEC_SHAPES(X) X(20, 10) X(20, 20) X(50, 50)   // BASELINE configs[1] (and [3] per rank), configs[2], configs[4]

@@ -256,7 +256,7 @@ struct DevState {
 // from the TQ base = base + dbytes).  State-sized QP vectors use the INTERNAL state order
 // [q(4) v(3) r(3) p(3)] (position last) and a stride of 16.
 struct Lds {
-  int X, U, x0, dbytes;
+  int X, U, x0, pre, dbytes;
   int AB, c, qv, r0, lb, ub, alpha, basis, wq;
   int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv, spv;
   int sub, rgp, qtotal;
@@ -273,6 +273,7 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   L.X = take((N + 1) * NX);
   L.U = take(N * NU);
   L.x0 = take(NX + 8);   // + [v_body(3), a_drag(3)] scratch of the post phase
+  L.pre = take(NX + 5);  // what the post phase reads of the persistent state, fetched in the load phase: x_pred_prev(13) | statistics(4) | has_prev
   L.dbytes = o * 8;
   o = 0;
   const int nv = N * NU;
@@ -309,7 +310,7 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   L.K = take(N * KS);
   L.Linv = take(N * 16);
   L.sF = take(4 * VS);
-  L.sT = take(3 * VS);
+  L.sT = take(4 * VS);   // rows 10..12 of T1'' (+ one row the fp64 hand-over writes unconditionally and nobody reads)
   L.stv = take(2 * VS);
   L.spv = take(VS);
   const int qp_end = o;
@@ -1053,6 +1054,12 @@ MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const L
   __syncthreads();
 }
 
+// A pinned input is eliminated from a stage by giving it an astronomically large diagonal entry instead of masking its row and
+// column: with Lambda_aa = D the LDL^T leaves l_ka = Lambda_ka / D (~1e-300), the other pivots change by Lambda_ka^2 / D (far below
+// one ulp), and the gain row K_a = O(1 / D) -- the same numbers as the masked elimination after rounding, without the mask
+// arithmetic on the critical path of every stage.  The pinned input itself is held at its bound by the caller.
+template <typename TQ> __device__ inline TQ pin_diag() { return sizeof(TQ) == 8 ? TQ(1e300) : TQ(1e30f); }
+
 // ------------------------------------------------------------------ QP: Riccati factorisation
 // Backward sweep recomputing P_i, K_i, Lambda_i^-1 for R~ = R + (polish ? 0 : ll/sl + lu/su) with inputs
 // pinned by `act` eliminated in polish mode, merged with the vector recursion for the linear term rho
@@ -1073,10 +1080,9 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
     const TQ rr = S[L.wq + 2 * VS + (i & 3)];
     TQ v;
     if (!polish) v = rr + S[L.ll + i] * trcp(S[L.sl + i]) + S[L.lu + i] * trcp(S[L.su + i]);
-    else v = S[L.act + i] != TQ(0) ? TQ(-1) : rr;
+    else v = S[L.act + i] != TQ(0) ? -pin_diag<TQ>() : rr;   // sign = pinned flag, magnitude = the diagonal the stage Hessian gets
     S[L.rt + i] = v;
   }
-  for (int it = lane; it < N * NU * 3; it += 64) S[L.K + (it / 3) * ABW + NX + it % 3] = 0;   // K pad columns
   const Sel<TQ> sel(h);
   const KMaj<TQ> km(L, N, h, c);
   // P_N = W_e as an accumulator tile: Pop[s] = P[RI(s,h)][c]; per-lane masks for the assembly of Q + G
@@ -1156,7 +1162,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
       const TQ fv = h >= 2 ? acc2[2] : acc2[3], tvv = h >= 2 ? acc1[2] : acc1[3];
       const int rr = h >= 2 ? h - 2 : h + 2;
       S[L.sF + rr * VS + c] = fv;
-      if (rr < 3) S[L.sT + rr * VS + c] = tvv;
+      S[L.sT + rr * VS + c] = tvv;   // rr == 3: the spare row
     }
     if (vl) {
       TQ idp[4];
@@ -1173,28 +1179,19 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
     // ---- Lambda = R~ + F_uu, LDL^T in registers (redundantly on every lane, straight-line code), then the solves
     TQ kk, mop, pcol;
     {
-      TQ Lm[4][4], mk[4];
+      TQ Lm[4][4];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int q = 0; q <= a; ++q) Lm[a][q] = S[L.sF + a * VS + 10 + q];
+      int pinv = 0;                          // bit a: input a of this stage is pinned (the same on every lane)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const TQ rt = S[L.rt + i * NU + a];
-        if (polish) {                      // pinned input: unit row/column, zero right-hand sides
-          mk[a] = rt < TQ(0) ? TQ(0) : TQ(1);
-          Lm[a][a] = mk[a] * (Lm[a][a] + rt) + (TQ(1) - mk[a]);
-        } else {
-          mk[a] = TQ(1);
-          Lm[a][a] += rt;
-        }
+        if (polish && rt < TQ(0)) pinv |= 1 << a;   // pinned input: diagonal pin_diag (see above), zero right-hand side of the feed-forward
+        Lm[a][a] += polish ? tabs(rt) : rt;
       }
-      if (polish) {
-#pragma unroll
-        for (int a = 1; a < 4; ++a)
-#pragma unroll
-          for (int q = 0; q < a; ++q) Lm[a][q] *= mk[a] * mk[q];
-      }
+      const int pinb = polish ? __builtin_amdgcn_readfirstlane(pinv) : 0;   // as a scalar: the branches below are scalar branches
       PF_FAC(12);                        // LDS hand-over + operand reads
       // LDL^T (no square roots; the reciprocal pivots are the only long-latency operations of the chain):
       // Lm[a][q] (a > q) becomes the unit-lower factor, cm the unscaled column entries l*d
@@ -1223,11 +1220,11 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
       for (int j = 0; j < 4; ++j) {
         const TQ mv = S[m3off + j * m3str];
         mvv[j] = mv;
-        y[j] = mk[j] * (c < NX ? mv : ((inv && vj == j) ? TQ(1) : TQ(0)));
+        y[j] = c < NX ? mv : ((inv && vj == j) ? TQ(1) : TQ(0));
         const TQ gu = S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j];     // gt = rho + B^T p
-        g[j] = mk[j] * gu;
+        g[j] = (pinb >> j) & 1 ? TQ(0) : gu;
         if (affine) gmax = tmax(gmax, tabs(g[j]));
-        if (affine && mrows && mk[j] == TQ(0)) {   // what the multiplier of a pinned input j needs: [M_j | F_uu row j | gt_j]
+        if (affine && mrows && ((pinb >> j) & 1)) {   // what the multiplier of a pinned input j needs: [M_j | F_uu row j | gt_j]
           if (h == 0 && c < NX) mrows[(i * NU + j) * MROW + c] = mv;
           else if (inv && vj == j) {
 #pragma unroll
@@ -1248,22 +1245,14 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
 #pragma unroll
         for (int k = cc + 1; k < 4; ++k) y[cc] -= Lm[k][cc] * y[k];
       }
-      if (polish) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] *= mk[j];
-      }
       // column lanes: K[:,c] = -y, p_i[c] = (A^T p)[c] - y.gt (+ q_i[c]); Lambda^-1 lanes: row vj = y, k_vj = -y.gt
       const TQ dot = y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3];
       const TQ tb = S[tboff];
-      if (h == 0 && c < NX) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) S[L.K + i * KS + j * ABW + c] = -y[j];
-      }
       if (inv) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) S[L.Linv + i * 16 + vj * 4 + j] = y[j];
         TQ kv = -dot;
-        if (polish) kv *= vj == 0 ? mk[0] : (vj == 1 ? mk[1] : (vj == 2 ? mk[2] : mk[3]));
+        if (polish && ((pinb >> vj) & 1)) kv = 0;
         S[L.vin + i * VS + vj] = kv;
       }
       TQ ex = tb - dot;
@@ -1273,6 +1262,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
       const TQ mh = h == 0 ? mvv[0] : (h == 1 ? mvv[1] : (h == 2 ? mvv[2] : mvv[3]));
       kk = c < NX ? -yh : TQ(0);
       mop = mmask * mh;
+      S[L.K + i * KS + h * ABW + c] = kk;   // K[h][c] from the lane that holds it; columns 13..15 are the zero pad of the row operands
     }
     PF_FAC(14);                          // right-hand sides, substitutions, stores of K, Lambda^-1
     if (i == 0) break;
@@ -1454,6 +1444,9 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
         for (int i = tid; i < nv; i += 64)
           if (S[L.act + i] == TQ(0)) dmin = tmin(dmin, tmin(-S[L.lb + i], S[L.ub + i]));
         keep_p = nact > 0 || wave_min(dmin) < TQ(0.1);
+#ifdef MPCQ_AB_NO_PSTORE   // A/B measurement only: no cost-to-go tiles, every factorisation starts at the last stage
+        keep_p = false;
+#endif
       }
       __syncthreads();
       for (int it = tid; it < N * VS; it += 64) {
@@ -2014,6 +2007,10 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     S[L.ub + it] = (TQ)(m.uub[k] - u);
   }
   if (tid < NX && !meas_from_plant) D[L.x0 + tid] = xm;
+  // the post phase's reads of the persistent state travel with the loads of this phase (three serial global round trips
+  // less behind the QP); a free-running launch keeps them in LDS from the second period on (lane 0 updates both copies)
+  if ((mode & MODE_POST) && (!C::RUN || period == 0) && tid < NX + 5)
+    D[L.pre + tid] = tid < NX ? st.xpp[(size_t)b * NX + tid] : (tid < NX + 4 ? st.stats[(size_t)b * 4 + (tid - NX)] : (double)st.has_prev[b]);
   // X -> LDS and qv = Q_i (X_i - xref_i) in one pass over the record
   for (int base = 0; base < (N + 1) * NX; base += 64 * UNR) {
     if (base > 0) load_block(base);
@@ -2135,7 +2132,7 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
   // ---- 4. post: nominal prediction, cursor, drag estimate, RGP regress, statistics
   const P<double> vbad = D + (L.x0 + NX);   // [v_body(3), a_drag(3)]
   const P<TQ> gCov = mk(st.C + (size_t)b * 3 * nb * nb, 3L * nb * nb, CK_C);
-  const P<double> gXpp = mk(st.xpp + (size_t)b * NX, NX, CK_XPP), gXpred = mk(st.xpred + (size_t)b * NX, NX, CK_XPRED);
+  const P<double> gXpp = mk(st.xpp + (size_t)b * NX, NX, CK_XPP), gXpred = mk(st.xpred + (size_t)b * NX, NX, CK_XPRED), pre = D + L.pre;
   const bool regress = gp && !(mode & MODE_STATIC_GP);
   if (regress) {   // stage the covariance while lane 0 integrates the nominal model (QP workspace is dead)
     for (int i = tid; i < 3 * nb * nb; i += 64) S[L.rgp + i] = gCov[i];
@@ -2149,9 +2146,9 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
     rk4_nominal(m, x, u, m.dt_pred, xp);
     // compute_a_drag (src/utils/utils.py:934-950) against the previous step's prediction
     double xq[NX];
-    const bool hp = st.has_prev[b] != 0;
+    const bool hp = pre[NX + 4] != 0.0;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) xq[k] = hp ? gXpp[k] : x[k];
+    for (int k = 0; k < NX; ++k) xq[k] = hp ? pre[k] : x[k];
     double R[9], Rq[9];
     rotmat(x + 3, R);
     rotmat(xq + 3, Rq);
@@ -2163,8 +2160,8 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
       vbad[3 + i] = (vb - vp) / m.dt_pred;
     }
 #pragma unroll
-    for (int k = 0; k < NX; ++k) { gXpred[k] = xp[k]; gXpp[k] = xp[k]; }
-    st.has_prev[b] = 1;
+    for (int k = 0; k < NX; ++k) { gXpred[k] = xp[k]; gXpp[k] = xp[k]; pre[k] = xp[k]; }
+    st.has_prev[b] = 1; pre[NX + 4] = 1.0;
     st.idx[b] = idx + 1;
     // tracking statistic against the first row of the reference chunk
     double ep = 0, ev = 0;
@@ -2174,7 +2171,11 @@ __global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> 
       ep += a * a; ev += c * c;
     }
     const P<double> gs = mk(st.stats + (size_t)b * 4, 4, CK_STATS);
-    gs[0] += ep; gs[1] += ev; gs[2] += 1; gs[3] = tmax(gs[3], ep);
+    {
+      const double s0 = pre[NX] + ep, s1 = pre[NX + 1] + ev, s2 = pre[NX + 2] + 1, s3 = tmax(pre[NX + 3], ep);
+      gs[0] = s0; gs[1] = s1; gs[2] = s2; gs[3] = s3;
+      pre[NX] = s0; pre[NX + 1] = s1; pre[NX + 2] = s2; pre[NX + 3] = s3;
+    }
     // trajectory finished (src/mpc_controller_node.py:374, evaluated after idx_traj += 1): the cursor stands on the last
     // row and the quadrotor is within EPSILON_TRAJECTORY_FINISHED of the first row of this step's chunk
     if ((mode & MODE_TRAJ) && idx + 2 == len && sqrt(ep) < m.finish_r) st.finished[b] = 1;

@@ -65,3 +65,17 @@ class SwarmLogger:
         xr = np.stack(self.rows["x_ref"])[:, :, :3]
         rms_k = np.sqrt(np.mean((x - xr) ** 2, axis=2))
         return np.sqrt(np.mean(rms_k ** 2, axis=0))
+
+    def cpu_time_summary(self):
+        """The CPU-time line of Visualiser.plot_data (src/Visualiser.py:981-987): avg_cpu = np.mean(t_cpu), std_cpu = np.std(t_cpu)
+        over the logged steps, in seconds.  Here t_cpu is the device time of the whole-batch launch of each step (the engine's
+        analogue of acados' 'time_tot'), identical for every quadrotor of the batch; returns (avg, std, per-quadrotor-share avg),
+        the last being avg / B -- the time one quadrotor's solve costs the device."""
+        t = np.stack(self.rows["t_cpu"])[:, 0, 0]
+        avg, std = float(np.mean(t)), float(np.std(t))
+        return avg, std, avg / self.engine.B
+
+    def summary_title(self):
+        """'MPC CPU Time, Avg: ..ms, STD: ..' as the reference's plot title prints it (src/Visualiser.py:987)."""
+        avg, std, _ = self.cpu_time_summary()
+        return f"MPC CPU Time, Avg: {avg * 1e3:.2f}ms, STD: {std * 1e3:.2f}"

@@ -110,6 +110,11 @@ def _reference_format_log(lib):
     st = e.get_tracking_stats()
     rms = lg.rms_position_error()
     assert np.isclose(np.sqrt(st[0] / (3 * st[2])), np.sqrt(np.mean(rms ** 2)), rtol=1e-9)
+    # the CPU-time summary of Visualiser.plot_data (src/Visualiser.py:981-987) over the same log
+    avg, std, per_quad = lg.cpu_time_summary()
+    t_cpu = np.array([q["t_cpu"][k, 0] for k in range(4)])
+    assert np.isclose(avg, np.mean(t_cpu)) and np.isclose(std, np.std(t_cpu)) and np.isclose(per_quad, avg / B) and avg >= 0
+    assert lg.summary_title().startswith("MPC CPU Time, Avg: ")
 
 
 def _free_running_equals_lockstep(lib):

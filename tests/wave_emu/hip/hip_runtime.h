@@ -105,6 +105,8 @@ inline int __builtin_amdgcn_readlane(int v, int src) {
   emu::sync();
   return r;
 }
+// v_readfirstlane_b32 with a full EXEC mask: lane 0's value
+inline int __builtin_amdgcn_readfirstlane(int v) { return __builtin_amdgcn_readlane(v, 0); }
 // v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C, lane (h = lane>>4, c = lane&15)
 // holds A[c][h], B[h][c]; C/D rows: f32 4h+reg, f64 h+4reg (MI355X_MICROARCH / cdna_hip_programming.md section 3)
 namespace emu { uint64_t* exchange2(); }
