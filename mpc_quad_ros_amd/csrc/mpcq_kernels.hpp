@@ -541,6 +541,14 @@ __device__ inline double trcp(double x) {
   r = fma(fma(-x, r, 1.0), r, r);   // v_rcp_f64 is good to ~2^-23: two steps reach the last ulp
   return fma(fma(-x, r, 1.0), r, r);
 }
+// pivot reciprocal of the stage Hessian: ONE Newton step on v_rcp_f64 (2^-23 -> ~2^-46 = 1.4e-14 relative).  The four pivots of
+// a stage are a serial chain (each step two dependent fp64 FMAs at ~16 cycles for a wave on its own); the gains inherit a
+// relative error of 1e-14, three orders below the rounding the recursion accumulates over a horizon anyway.
+__device__ inline float  trcp1(float x)  { return __fdividef(1.0f, x); }
+__device__ inline double trcp1(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+}
 __device__ inline float  tabs(float x)  { return fabsf(x); }
 __device__ inline double tabs(double x) { return fabs(x); }
 
@@ -1137,6 +1145,10 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
     if (affine) with_gap(i > 0 ? i - 1 : 0, nxt);
     TQ qvi = 0;
     if (affine) qvi = A[L.qv + i * VS + b3];   // consumed at the end of the stage
+    // what the solve needs and does not depend on this stage's products: read now, behind the tile products
+    TQ rtv[4], rhov[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { rtv[a] = S[L.rt + i * NU + a]; rhov[a] = S[L.rho + i * NU + a]; }
     TQ acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc1, Pop[s], cur[s]);              // T1''
@@ -1172,29 +1184,35 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
       vl_store(S + L.stv + VS, h, acc2);                         // rows 0..9: A^T p ; rows 10..13: B^T p
     }
     __syncthreads();
-    // transposed T1'' elements of the position columns of P_i: read now, consumed by the P update behind the solve
-    TQ tT[4];
+    // ---- everything the solve reads from the hand-over, as ONE batch of LDS reads (no branch in between: the compiler
+    //      issues them back to back and the LDL^T starts on the first arrivals)
+    TQ tT[4], Lm[4][4], mvv[4], gu[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) tT[s] = S[toff[s]];
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q <= a; ++q) Lm[a][q] = S[L.sF + a * VS + 10 + q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mvv[j] = S[m3off + j * m3str];                                 // M[j][c]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gu[j] = rhov[j] + S[L.stv + VS + 10 + j];                        // gt = rho + B^T p
+    const TQ tb = S[tboff];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tT[s] = S[toff[s]];   // transposed T1'' elements of the position columns of P_i (P update)
     // ---- Lambda = R~ + F_uu, LDL^T in registers (redundantly on every lane, straight-line code), then the solves
     TQ kk, mop, pcol;
+    int pinb = 0;
     {
-      TQ Lm[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q <= a; ++q) Lm[a][q] = S[L.sF + a * VS + 10 + q];
       int pinv = 0;                          // bit a: input a of this stage is pinned (the same on every lane)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const TQ rt = S[L.rt + i * NU + a];
-        if (polish && rt < TQ(0)) pinv |= 1 << a;   // pinned input: diagonal pin_diag (see above), zero right-hand side of the feed-forward
-        Lm[a][a] += polish ? tabs(rt) : rt;
+        if (polish && rtv[a] < TQ(0)) pinv |= 1 << a;   // pinned input: diagonal pin_diag (see above), zero right-hand side of the feed-forward
+        Lm[a][a] += polish ? tabs(rtv[a]) : rtv[a];
       }
-      const int pinb = polish ? __builtin_amdgcn_readfirstlane(pinv) : 0;   // as a scalar: the branches below are scalar branches
       PF_FAC(12);                        // LDS hand-over + operand reads
       // LDL^T (no square roots; the reciprocal pivots are the only long-latency operations of the chain):
-      // Lm[a][q] (a > q) becomes the unit-lower factor, cm the unscaled column entries l*d
+      // Lm[a][q] (a > q) becomes the unit-lower factor, cm the unscaled column entries l*d.  (An explicit inverse by 2x2 blocks --
+      // two reciprocals in series instead of four -- was measured in rounds 2 and 3: 1.3 % slower in fp64, and the fp32 mode
+      // loses two orders of magnitude in accuracy with it.)
       TQ id[4], cm[4][4];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
@@ -1203,7 +1221,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
         for (int k = 0; k < cc; ++k) d -= Lm[cc][k] * cm[cc][k];
         if (!(d > TQ(0))) ok = false;
         d = d > TQ(0) ? d : TQ(1);
-        id[cc] = trcp(d);
+        id[cc] = trcp1(d);
 #pragma unroll
         for (int a = cc + 1; a < 4; ++a) {
           TQ s2 = Lm[a][cc];
@@ -1215,24 +1233,9 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
       }
       PF_FAC(13);                        // 4x4 LDL^T
       // rhs: M[:,c] on the lanes of column c < 13, e_vj on the four Lambda^-1 lanes
-      TQ y[4], g[4], mvv[4];
+      TQ y[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const TQ mv = S[m3off + j * m3str];
-        mvv[j] = mv;
-        y[j] = c < NX ? mv : ((inv && vj == j) ? TQ(1) : TQ(0));
-        const TQ gu = S[L.rho + i * NU + j] + S[L.stv + VS + 10 + j];     // gt = rho + B^T p
-        g[j] = (pinb >> j) & 1 ? TQ(0) : gu;
-        if (affine) gmax = tmax(gmax, tabs(g[j]));
-        if (affine && mrows && ((pinb >> j) & 1)) {   // what the multiplier of a pinned input j needs: [M_j | F_uu row j | gt_j]
-          if (h == 0 && c < NX) mrows[(i * NU + j) * MROW + c] = mv;
-          else if (inv && vj == j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) mrows[(i * NU + j) * MROW + NX + q] = S[L.sF + j * VS + 10 + q];
-            mrows[(i * NU + j) * MROW + NX + 4] = gu;
-          }
-        }
-      }
+      for (int j = 0; j < 4; ++j) y[j] = c < NX ? mvv[j] : ((inv && vj == j) ? TQ(1) : TQ(0));
 #pragma unroll
       for (int cc = 1; cc < 4; ++cc) {
 #pragma unroll
@@ -1245,28 +1248,33 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
 #pragma unroll
         for (int k = cc + 1; k < 4; ++k) y[cc] -= Lm[k][cc] * y[k];
       }
-      // column lanes: K[:,c] = -y, p_i[c] = (A^T p)[c] - y.gt (+ q_i[c]); Lambda^-1 lanes: row vj = y, k_vj = -y.gt
-      const TQ dot = y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3];
-      const TQ tb = S[tboff];
-      if (inv) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) S[L.Linv + i * 16 + vj * 4 + j] = y[j];
-        TQ kv = -dot;
-        if (polish && ((pinb >> vj) & 1)) kv = 0;
-        S[L.vin + i * VS + vj] = kv;
-      }
-      TQ ex = tb - dot;
-      if (affine) ex += qvi;                // stage gradient q_i enters the recursion directly
-      pcol = c < NX ? ex : TQ(0);
+      // operands of the P update first: they head the chain into the next stage
       const TQ yh = h == 0 ? y[0] : (h == 1 ? y[1] : (h == 2 ? y[2] : y[3]));
       const TQ mh = h == 0 ? mvv[0] : (h == 1 ? mvv[1] : (h == 2 ? mvv[2] : mvv[3]));
       kk = c < NX ? -yh : TQ(0);
       mop = mmask * mh;
+      // column lanes: K[:,c] = -y, p_i[c] = (A^T p)[c] - y.gt (+ q_i[c]); Lambda^-1 lanes: row vj = y, k_vj = -y.gt
+      pinb = polish ? __builtin_amdgcn_readfirstlane(pinv) : 0;   // as a scalar: the tests below are scalar selects / branches
+      TQ dot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const TQ gj = (pinb >> j) & 1 ? TQ(0) : gu[j];
+        dot += y[j] * gj;
+        if (affine) gmax = tmax(gmax, tabs(gj));
+      }
+      TQ ex = tb - dot;
+      if (affine) ex += qvi;                // stage gradient q_i enters the recursion directly
+      pcol = c < NX ? ex : TQ(0);
       S[L.K + i * KS + h * ABW + c] = kk;   // K[h][c] from the lane that holds it; columns 13..15 are the zero pad of the row operands
+      if (inv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[L.Linv + i * 16 + vj * 4 + j] = y[j];
+        S[L.vin + i * VS + vj] = (polish && ((pinb >> vj) & 1)) ? TQ(0) : -dot;
+      }
     }
     PF_FAC(14);                          // right-hand sides, substitutions, stores of K, Lambda^-1
-    if (i == 0) break;
     // ---- P_i = Q + G + M^T K as one k=4 tile on top of the assembled C operand; p_i back to column 14 through DPP
+    //      (also at i = 0, where nobody uses it: one tile product per factorisation instead of a branch in the chain)
     {
       TQ C4[4];
 #pragma unroll
@@ -1276,13 +1284,27 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
 #pragma unroll
       for (int s = 0; s < 4; ++s) { Pop[s] = C4[s]; cur[s] = nxt[s]; }
       l2g<TQ>(pcol, h, pv);
-      if (pstore) {   // cost-to-go of this stage, for a later restart below it
+    }
+    // ---- behind the chain: what the multiplier of a pinned input j needs [M_j | F_uu row j | gt_j], the cost-to-go tile
+    if (affine && mrows && pinb) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) pstore[i * PST + lane * 4 + s] = Pop[s];
-        if (vl) {
+      for (int j = 0; j < 4; ++j) {
+        if (!((pinb >> j) & 1)) continue;
+        if (h == 0 && c < NX) mrows[(i * NU + j) * MROW + c] = mvv[j];
+        else if (inv && vj == j) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) pstore[i * PST + 256 + RI<TQ>(s, h)] = pv[s];
+          for (int q = 0; q < 4; ++q) mrows[(i * NU + j) * MROW + NX + q] = S[L.sF + j * VS + 10 + q];
+          mrows[(i * NU + j) * MROW + NX + 4] = gu[j];
         }
+      }
+    }
+    if (i == 0) break;
+    if (pstore) {   // cost-to-go of this stage, for a later restart below it
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pstore[i * PST + lane * 4 + s] = Pop[s];
+      if (vl) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pstore[i * PST + 256 + RI<TQ>(s, h)] = pv[s];
       }
     }
     __syncthreads();   // the hand-over arrays are rewritten by the next stage

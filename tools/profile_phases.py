@@ -23,7 +23,7 @@ def main():
     prec = 1 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else 0
     B, N, nb = 1024, 20, 10
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-    lib = os.path.join(ROOT, "mpc_quad_ros_amd", "libmpcq_prof.so")
+    lib = os.path.join(ROOT, "mpc_quad_ros_amd", "libmpcq_prof_fac.so" if os.environ.get("PROF_MODE") == "fac" else "libmpcq_prof.so")
     import bench
     refs = bench.workload(2026, 0, B, int(os.environ.get('PREROLL', bench.PREROLL)) + steps)
     e, _ = bench.make_engine(B, N, nb, prec, 0, 0, 2026, lib_path=lib, refs=refs)      # the bench workload (min-snap references)

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r2_final"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r3_final"
 ROUND = TAG.split("_")[0]     # r2_final -> r2: prefix of the traffic file bench.py picks up
 O = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
@@ -55,7 +55,7 @@ for grp in ("fetch", "write", "sq", "mfma", "mem"):
     for k in acc:
         pmc[k] = acc[k] / cnt[k]
         pmc["launches_" + grp] = cnt[k]
-pmc["note"] = "per-launch means over the lockstep step_kernel launches (warm-up + timed steps) of the SAME command as the bench line and the kernel trace (`bench.py --no-cpu-baseline --no-alt`); one rocprofv3 --pmc pass per group"
+pmc["note"] = "per-launch means over the lockstep step_kernel launches (warm-up + timed steps) of the SAME command as the bench line and the kernel trace (`bench.py --no-cpu-baseline --no-alt --no-configs --no-parity` + the tag's arguments); one rocprofv3 --pmc pass per group"
 with open(os.path.join(P, f"{TAG}_pmc.json"), "w") as f:
     json.dump(pmc, f, indent=1)
 prec = bench["dtype"]
@@ -67,7 +67,20 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
          "hbm_bytes_per_launch_fetch_x2_upper_bound": (2 * fk + wk) * 1024.0,
          "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
          "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-counts wide (16 B/lane) coalesced reads by 2x; this kernel reads 8 B/lane records, so the raw sum is reported as `traffic` and the x2-fetch figure as an upper bound.  With the stage records (AB'', gaps, cost gradients: 38.6 KB per instance in fp64) placed in global memory the traffic counted at the L2 boundary includes their write-out and the re-reads that miss L2: that is the price of running 4 instead of 2 instances per CU (DESIGN.md section 3.1)."}
-    with open(os.path.join(P, f"{ROUND}_pmc_traffic_{prec}.json"), "w") as f:
+    # identity of the build and of the command line: bench.py attaches the traffic only to a run of the same build and arguments
+    sys.path.insert(0, ROOT)
+    import bench as _bench
+    cfg = bench["config"]
+    t["source_sha16"] = _bench.kernel_source_sha16()
+    t["args"] = {"steps": bench["steps"], "warmup": bench["warmup"], "preroll": cfg["preroll_periods"], "seed": int(os.environ.get("BENCH_SEED", "2026")),
+                 "batch": cfg["batch_per_gpu"], "N": cfg["horizon_nodes"], "nb": cfg["rgp_basis"], "precision": prec}
+    t["command"] = "python3 bench.py --no-cpu-baseline --no-alt --no-configs --no-parity " + open(os.path.join(O, f"args_{TAG}.txt")).read().strip()
+    try:
+        import subprocess
+        t["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip() + " (+ working tree at collection time)"
+    except Exception:
+        t["commit"] = None
+    with open(os.path.join(P, f"{ROUND}_pmc_traffic_{prec}_{TAG}.json"), "w") as f:
         json.dump(t, f, indent=1)
     print("traffic bytes/launch", t["hbm_bytes_per_launch"], "algorithmic", t["algorithmic_bytes_per_launch"])
     # the bench line of this collection was printed before these counters existed: record them in the tracked copy
