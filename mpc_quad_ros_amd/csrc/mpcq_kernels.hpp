@@ -293,6 +293,9 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   }
   L.mrow = gtake(N * MROW * NU);
   L.pst = gtake(N * PST);
+#ifdef MPCQ_AB_PSTORE_DOUBLE   // A/B measurement only: every cost-to-go tile is written twice (what do the stores cost?)
+  gtake(N * PST);
+#endif
   L.gtotal = (g + 15) & ~15;
   L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv);
   L.alpha = take(3 * nb);
@@ -1159,6 +1162,14 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc2, cur[s], b2[s]);               // F'' ; column 14 = AB''^T p
     PF_FAC(11);                          // two tile products (8 MFMA)
+    // The ten entries of the stage Hessian come straight out of the accumulator tile through v_readlane (F''[10+a][10+q] is
+    // register in_s(a) of lane (in_h(a), 10+q)): the LDL^T starts on them while the LDS round trip of everything else -- needed
+    // only behind the factorisation -- is still in flight.
+    TQ Lm[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q <= a; ++q) Lm[a][q] = bc(acc2[in_s<TQ>(a)], 16 * in_h<TQ>(a) + 10 + q);
     // hand rows 10..13 over to the stage-Hessian lanes through LDS
     if (sizeof(TQ) == 4) {
       if (h >= 2) {   // h = 2: registers 2,3 = rows 10,11 ; h = 3: registers 0,1 = rows 12,13
@@ -1186,11 +1197,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
     __syncthreads();
     // ---- everything the solve reads from the hand-over, as ONE batch of LDS reads (no branch in between: the compiler
     //      issues them back to back and the LDL^T starts on the first arrivals)
-    TQ tT[4], Lm[4][4], mvv[4], gu[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int q = 0; q <= a; ++q) Lm[a][q] = S[L.sF + a * VS + 10 + q];
+    TQ tT[4], mvv[4], gu[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) mvv[j] = S[m3off + j * m3str];                                 // M[j][c]
 #pragma unroll
@@ -1302,6 +1309,10 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
     if (pstore) {   // cost-to-go of this stage, for a later restart below it
 #pragma unroll
       for (int s = 0; s < 4; ++s) pstore[i * PST + lane * 4 + s] = Pop[s];
+#ifdef MPCQ_AB_PSTORE_DOUBLE
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pstore[(N + i) * PST + lane * 4 + s] = Pop[s];
+#endif
       if (vl) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) pstore[i * PST + 256 + RI<TQ>(s, h)] = pv[s];

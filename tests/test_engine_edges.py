@@ -86,6 +86,40 @@ def _argument_errors(lib):
         e.set_trajectories(np.zeros((2, 10, 13)))
     with pytest.raises(_lib.MpcqError):
         e.set_trajectories(np.zeros((1, 10, 13)), np.array([11]))
+    # solver tuning is validated, not read from the environment
+    for bad in (dict(warm_max=-3), dict(warm_max=1000), dict(pin_ratio=-1.0), dict(ipm_mu0=5.0), dict(ipm_margin=0.7), dict(stage_mem=3),
+                dict(flip_max=-2), dict(ipm_tol=float("nan"))):
+        with pytest.raises(_lib.MpcqError, match="tune"):
+            Engine(EngineConfig(batch=1, N=5, tune=bad), lib_path=lib)
+    Engine(EngineConfig(batch=1, N=5, tune=dict(warm_max=8, flip_max=-1, abort_pins=-1, stage_mem="global", pin_ratio=0.5)), lib_path=lib).close()
+    with pytest.raises(ValueError, match="unknown tuning field"):
+        EngineConfig(batch=1, N=5, tune=dict(warm=3)).to_c()
+    _versioned_create(lib)
+
+
+def _versioned_create(lib_path):
+    """mpcq_create_sized: a caller built against an older header passes ITS struct size; fields behind it take their defaults,
+    garbage behind the declared size is never read; sizes the library does not understand are refused."""
+    import ctypes
+    from mpc_quad_ros_amd.params import CConfig
+    lib = _lib.load(lib_path)
+    c = EngineConfig(batch=2, N=5).to_c()
+    raw = (ctypes.c_char * (ctypes.sizeof(CConfig) + 64))()
+    ctypes.memmove(raw, ctypes.byref(c), ctypes.sizeof(CConfig))
+    old_size = CConfig.finish_radius.offset                      # the 0.1 layout: ends before finish_radius
+    ctypes.memset(ctypes.addressof(raw) + old_size, 0xAB, ctypes.sizeof(CConfig) + 64 - old_size)   # garbage where newer fields would be
+    h = ctypes.c_void_p()
+    assert lib.mpcq_create_sized(ctypes.cast(raw, ctypes.c_void_p), old_size, ctypes.byref(h)) == 0, lib.mpcq_last_error()
+    lib.mpcq_destroy(h)
+    v03 = CConfig.tune.offset                                    # the 0.2 layout: ends behind finish_radius
+    c2 = EngineConfig(batch=2, N=5, finish_radius=0.5).to_c()
+    ctypes.memmove(raw, ctypes.byref(c2), v03)
+    assert lib.mpcq_create_sized(ctypes.cast(raw, ctypes.c_void_p), v03, ctypes.byref(h)) == 0, lib.mpcq_last_error()
+    lib.mpcq_destroy(h)
+    for size in (CConfig.device.offset, ctypes.sizeof(CConfig) + 8):
+        assert lib.mpcq_create_sized(ctypes.cast(raw, ctypes.c_void_p), size, ctypes.byref(h)) != 0
+        assert b"size" in lib.mpcq_last_error()
+    assert b"0.3" in lib.mpcq_version()
 
 
 def _reference_format_log(lib):
