@@ -449,7 +449,11 @@ def main():
                                      "random-waypoint min-snap flights (3 waypoints each, v_max=a_max=12)",
                        "batch_per_gpu": B, "global_batch": B * world, "horizon_nodes": N, "rgp_basis": nb, "preroll_periods": args.preroll,
                        "parallelism": f"shard{world}" if world > 1 else "single", "threads_per_quad": 64,
-                       "stats_reduce": stats_reduce, "rccl_ok": world == 1 or stats_reduce == "rccl"},
+                       "stats_reduce": stats_reduce, "rccl_ok": world == 1 or stats_reduce == "rccl",
+                       "scaling_note": ("weak scaling at 8192 quadrotors per GPU for every N > 1 (N = 8 is BASELINE configs[3], 65 536 quadrotors); the N = 1 "
+                                        "line is configs[1] (1024 quadrotors, one wave per SIMD) -- the one-GPU reference point for the N > 1 lines is the "
+                                        "'configs[3] per rank' entry under `configs` of the N = 1 line") if world > 1 else
+                                       "one GPU: BASELINE configs[1]; under WORLD_SIZE > 1 the default is 8192 quadrotors per GPU (configs[3])"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": f"mpcq::step_kernel<{'double' if prec == PRECISION_F64 else 'float'}>",
