@@ -5,8 +5,9 @@
 // (sensitivities AB'', shooting gaps, cost gradients) live in LDS or, when that lets the whole batch be
 // resident at once, in a per-instance global record streamed through L2 (Cfg::GAB).  HBM is touched once
 // per step to load and once to store the persistent state, with lane-contiguous (coalesced) records.
-// The vectors of the Riccati / adjoint / rollout recursions ride in pad column 14 of the matrix-core tiles,
-// so the N-stage sweeps run without LDS round trips or barriers on their critical path.
+// The Riccati factorisation runs its matrix-matrix products on the matrix cores (the recursion vector rides in pad column 14
+// of the tiles); the matrix-vector sweeps run on the vector ALU with permlane / DPP cross-lane traffic, without LDS round
+// trips or barriers on their critical path.
 //
 // Precision: the SQP iterate (X, U), the measurement, the reference and every difference that
 // defines the QP data (x0 - X0, X_i - xref_i, U_i - uref_i, bounds, shooting gaps) are formed in
@@ -258,7 +259,7 @@ struct DevState {
 struct Lds {
   int X, U, x0, pre, dbytes;
   int AB, c, qv, r0, lb, ub, alpha, basis, wq;
-  int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv, spv;
+  int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv;
   int sub, rgp, qtotal;
   int gab, zb, gx, gtotal;   // stage data (AB'', c, qv) in global memory? ; LDS zero block ; GP exchange scratch ; global elements per instance
   int mrow;                  // multiplier rows (always global): per stage 4 rows [M_a(13) | F_uu row(4) | gt_a | pad 2]
@@ -315,7 +316,6 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   L.sF = take(4 * VS);
   L.sT = take(4 * VS);   // rows 10..12 of T1'' (+ one row the fp64 hand-over writes unconditionally and nobody reads)
   L.stv = take(2 * VS);
-  L.spv = take(VS);
   const int qp_end = o;
   L.rgp = u0;
   const int rgp_end = u0 + al4(3 * nb * nb) + 5 * al4(3 * nb) + 32;
@@ -362,10 +362,31 @@ __device__ inline double bc(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 // DPP lane permutes inside 16-lane rows (quad_perm / row_ror), no LDS involved
-template <int CTRL> __device__ inline int dpp(int v) { CK_EXEC_FULL(2); return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+// (old operand undefined + bound_ctrl: every use runs with a full EXEC mask and permutes inside a row, so no source lane is ever
+// invalid -- and the compiler needs no copy of the source in front of each v_mov_dpp)
+template <int CTRL> __device__ inline int dpp(int v) { CK_EXEC_FULL(2); return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 template <int CTRL> __device__ inline float dpp(float v) { return __int_as_float(dpp<CTRL>(__float_as_int(v))); }
-template <int CTRL> __device__ inline double dpp(double v) {
+template <int CTRL> __device__ inline double dpp(double v) {   // one v_mov_b64_dpp for row_newbcast (the only 64-bit DPP of gfx950), two 32-bit ones otherwise
+#if defined(__AMDGCN__) || defined(MPCQ_EMU_BUILD)
+  CK_EXEC_FULL(2);
+  const long long x = __builtin_bit_cast(long long, v);
+  return __builtin_bit_cast(double, (long long)__builtin_amdgcn_update_dpp(0ll, x, CTRL, 0xF, 0xF, true));
+#else   // host pass of hipcc (parses device code, never runs it): the builtin is only declared for 32 bits there
   return __hiloint2double(dpp<CTRL>(__double2hiint(v)), dpp<CTRL>(__double2loint(v)));
+#endif
+}
+// DPP permutation applied to the 16-lane rows selected by ROWS (bit r = row r of the wave) only; the other rows keep their value:
+// the row-conditional rotates of l2g in ONE instruction per dword (DPP row_mask) instead of a permute plus a select
+template <int CTRL, int ROWS> __device__ inline int dpp_rows(int v) { CK_EXEC_FULL(2); return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xF, false); }
+template <int CTRL, int ROWS> __device__ inline float dpp_rows(float v) { return __int_as_float(dpp_rows<CTRL, ROWS>(__float_as_int(v))); }
+template <int CTRL, int ROWS> __device__ inline double dpp_rows(double v) {
+#if defined(__AMDGCN__) || defined(MPCQ_EMU_BUILD)
+  CK_EXEC_FULL(2);
+  const long long x = __builtin_bit_cast(long long, v);
+  return __builtin_bit_cast(double, (long long)__builtin_amdgcn_update_dpp(x, x, CTRL, ROWS, 0xF, false));
+#else
+  return __hiloint2double(dpp_rows<CTRL, ROWS>(__double2hiint(v)), dpp_rows<CTRL, ROWS>(__double2loint(v)));
+#endif
 }
 // sum over the four 16-lane rows (lanes c, c+16, c+32, c+48), result on every lane: after v_permlane16_swap(v, v) the two
 // outputs hold rows (0,0,2,2) and (1,1,3,3), after v_permlane32_swap rows (0,1,0,1) and (2,3,2,3) -- their sum is the
@@ -427,17 +448,14 @@ template <typename TQ> __device__ inline int RI(int s, int h) { return sizeof(TQ
 // h holds x[RI(s,h)], s = 0..3) without LDS: rotate row h left by U*h lanes (two conditional row_ror; U = 1 for the f64 slot
 // map h + 4s, 4 for the f32 map 4h + s), then row_newbcast of the lane that now holds the slot.
 template <typename TQ> __device__ inline void l2g(TQ x, int h, TQ (&v)[4]) {
+  (void)h;
   if (sizeof(TQ) == 8) {
-    const TQ r1 = dpp<0x12F>(x);            // row_ror:15 -> lane c <- lane c + 1
-    x = (h & 1) ? r1 : x;
-    const TQ r2 = dpp<0x12E>(x);            // row_ror:14 -> lane c <- lane c + 2
-    x = (h & 2) ? r2 : x;
+    x = dpp_rows<0x12F, 0xA>(x);            // rows 1, 3: row_ror:15 -> lane c <- lane c + 1
+    x = dpp_rows<0x12E, 0xC>(x);            // rows 2, 3: row_ror:14 -> lane c <- lane c + 2
     v[0] = dpp<0x150>(x); v[1] = dpp<0x154>(x); v[2] = dpp<0x158>(x); v[3] = dpp<0x15C>(x);   // row_newbcast:0,4,8,12
   } else {
-    const TQ r1 = dpp<0x12C>(x);            // row_ror:12 -> lane c <- lane c + 4
-    x = (h & 1) ? r1 : x;
-    const TQ r2 = dpp<0x128>(x);            // row_ror:8  -> lane c <- lane c + 8
-    x = (h & 2) ? r2 : x;
+    x = dpp_rows<0x12C, 0xA>(x);            // rows 1, 3: row_ror:12 -> lane c <- lane c + 4
+    x = dpp_rows<0x128, 0xC>(x);            // rows 2, 3: row_ror:8  -> lane c <- lane c + 8
     v[0] = dpp<0x150>(x); v[1] = dpp<0x151>(x); v[2] = dpp<0x152>(x); v[3] = dpp<0x153>(x);   // row_newbcast:0..3
   }
 }
@@ -853,7 +871,8 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L
 // dx_0 = x0 - X_0, lb <= du <= ub.  Q_i = h W_x (i<N) / W_e, R = h W_u diagonal; qv, r0, lb, ub, c prepared by
 // the caller (internal state order).  With position last, [A|B] = [AB''(:,0:10) | [0;I] | AB''(:,10:14)]: the 14
 // columns of AB'' (10 states q,v,r + 4 inputs) fit one 16-wide matrix-core tile and the position columns
-// are handled as identity.  All sweeps are matrix-core products with the vector riding in column 14.
+// are handled as identity.  The factorisation uses tile products; the sweeps multiply the same operand registers by ONE vector on
+// the vector ALU (riccati_forward).
 
 // per-lane slot classes of the four registers of a column-14 vector, as 0/1 multipliers
 template <typename TQ> struct Sel {
@@ -980,11 +999,8 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, con
       const TQ t = hsum((qa[0][0] * pv[0] + qa[0][1] * pv[1]) + (qa[0][2] * pv[2] + qa[0][3] * pv[3]));   // (AB''^T p)[c]
       const TQ gt = t + rvc;                                   // gt_j = rho_j + (B^T p)_j on lane column 10 + j
       // row h needs gt_h on every lane: rotate row h left by h lanes, broadcast lane 10
-      TQ r = gt;
-      const TQ r1 = dpp<0x12F>(r);
-      r = (h & 1) ? r1 : r;
-      const TQ r2 = dpp<0x12E>(r);
-      r = (h & 2) ? r2 : r;
+      TQ r = dpp_rows<0x12F, 0xA>(gt);
+      r = dpp_rows<0x12E, 0xC>(r);
       const TQ gh = dpp<0x15A>(r);
       pc = (arow ? t : (prow ? pc : TQ(0))) + hsum(kk * gh);   // p_i = A^T p_{i+1} + K^T gt (pinned rows of K are 0)
       TQ g[4];

@@ -141,8 +141,7 @@ typedef double emu_d4 __attribute__((ext_vector_type(4)));
 inline emu_f4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f4 c, int, int, int) { return emu_mfma<float, emu_f4, false>(a, b, c); }
 inline emu_d4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emu_d4 c, int, int, int) { return emu_mfma<double, emu_d4, true>(a, b, c); }
 // DPP: quad_perm (ctrl 0x00..0xFF), row_ror:n (0x121..0x12F) and row_newbcast:n (0x150..0x15F) with all rows/banks enabled
-inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool) {
-  (void)old;
+inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int row_mask, int, bool) {
   uint64_t* ex = emu::exchange();
   const unsigned t = emu::cur->tid.x;
   ex[t] = (uint32_t)v;
@@ -154,9 +153,15 @@ inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int, int, bool)
   else if (ctrl >= 0x121 && ctrl <= 0x12F) src = (t & ~15u) | ((t - (unsigned)(ctrl - 0x120)) & 15u);
   else if (ctrl >= 0x150 && ctrl <= 0x15F) src = (t & ~15u) | (unsigned)(ctrl - 0x150);   // row_newbcast:n (gfx90a+)
   else { std::abort(); }
-  const int r = (int)(uint32_t)ex[src];
+  const int r = ((row_mask >> ((t & 63u) >> 4)) & 1) ? (int)(uint32_t)ex[src] : old;   // rows outside row_mask keep `old`
   emu::sync();
   return r;
+}
+// 64-bit form (v_mov_b64_dpp for row_newbcast, two 32-bit moves otherwise): both halves take the same lane permutation
+inline long long __builtin_amdgcn_update_dpp(long long old, long long v, int ctrl, int rm, int bm, bool bc) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)old, (int)(unsigned)v, ctrl, rm, bm, bc);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)((unsigned long long)old >> 32), (int)(unsigned)((unsigned long long)v >> 32), ctrl, rm, bm, bc);
+  return (long long)(((unsigned long long)hi << 32) | lo);
 }
 // v_permlane32_swap_b32 (gfx950): lanes 32..63 of `a` are exchanged with lanes 0..31 of `b`; returns {new a, new b}
 typedef unsigned emu_u2 __attribute__((ext_vector_type(2)));
