@@ -19,24 +19,30 @@
 namespace mpcq {   // mpcq_spec.hip, one translation unit per specialised shape
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
 #if defined(MPCQ_CHECKED) || defined(MPCQ_ONE_SHAPE)   // the checked build compiles for tens of minutes per specialised shape: only the headline shape has one there (MPCQ_ONE_SHAPE: quick A/B variants, `make variant SHAPES=20_10 EXTRA=-DMPCQ_ONE_SHAPE`)
-#define MPCQ_SPEC_SHAPES(X) X(20, 10)
+#ifndef MPCQ_ONE_N
+#define MPCQ_ONE_N 20
+#define MPCQ_ONE_NB 10
+#endif
+#define MPCQ_SPEC_SHAPES(X) X(MPCQ_ONE_N, MPCQ_ONE_NB)
 #else
 #define MPCQ_SPEC_SHAPES(X) X(20, 10) X(20, 20) X(50, 50)   // BASELINE configs[1] (and [3] per rank), configs[2], configs[4]
 #endif
-#define MPCQ_DECL(n, nb) StepFn<double> spec_step_f64_##n##_##nb(bool gab, bool run); StepFn<float> spec_step_f32_##n##_##nb(bool gab, bool run);
+// (one more macro level so that shapes given as macros -- MPCQ_ONE_N -- are expanded before the names are pasted)
+#define MPCQ_DECL_(n, nb) StepFn<double> spec_lock_f64_##n##_##nb(bool gab); StepFn<float> spec_lock_f32_##n##_##nb(bool gab);
+#define MPCQ_DECL(n, nb) MPCQ_DECL_(n, nb)
 MPCQ_SPEC_SHAPES(MPCQ_DECL)
 #undef MPCQ_DECL
 }
-static mpcq::StepFn<double> spec_step(int N, int nb, bool gab, bool run, double*) {
-#define MPCQ_TRY(n, nb_) if (N == n && nb == nb_) return mpcq::spec_step_f64_##n##_##nb_(gab, run);
-  MPCQ_SPEC_SHAPES(MPCQ_TRY)
-#undef MPCQ_TRY
+#define MPCQ_TRY64_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_lock_f64_##n##_##nb_(gab);
+#define MPCQ_TRY32_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_lock_f32_##n##_##nb_(gab);
+#define MPCQ_TRY64(n, nb_) MPCQ_TRY64_(n, nb_)
+#define MPCQ_TRY32(n, nb_) MPCQ_TRY32_(n, nb_)
+static mpcq::StepFn<double> spec_step(int N, int nb, bool gab, double*) {   // lockstep instance of a specialised shape, or nullptr
+  MPCQ_SPEC_SHAPES(MPCQ_TRY64)
   return nullptr;
 }
-static mpcq::StepFn<float> spec_step(int N, int nb, bool gab, bool run, float*) {
-#define MPCQ_TRY(n, nb_) if (N == n && nb == nb_) return mpcq::spec_step_f32_##n##_##nb_(gab, run);
-  MPCQ_SPEC_SHAPES(MPCQ_TRY)
-#undef MPCQ_TRY
+static mpcq::StepFn<float> spec_step(int N, int nb, bool gab, float*) {
+  MPCQ_SPEC_SHAPES(MPCQ_TRY32)
   return nullptr;
 }
 
@@ -369,11 +375,11 @@ struct EngineT : mpcq_engine {
     lds_bytes = gab ? bg : bl;
     if ((rc = dalloc(st.stage, Bz * L.gtotal))) return rc;   // stage records (global placement) + multiplier rows
     kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false>>;
-    // shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
+    // free-running launches (mpcq_sim_run): the any-shape instance for every shape (mpcq_spec.hip says why)
     krun = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false, 0, -1, true>>;
+    // lockstep launches: shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
     if (!ienv("MPCQ_GENERIC", tu.generic_kernel)) {
-      if (auto k = spec_step(N, nb, gab, false, (T*)nullptr)) kstep = k;
-      if (auto k = spec_step(N, nb, gab, true, (T*)nullptr)) krun = k;
+      if (auto k = spec_step(N, nb, gab, (T*)nullptr)) kstep = k;
     }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -375,18 +375,13 @@ template <int CTRL> __device__ inline double dpp(double v) {   // one v_mov_b64_
   return __hiloint2double(dpp<CTRL>(__double2hiint(v)), dpp<CTRL>(__double2loint(v)));
 #endif
 }
-// DPP permutation applied to the 16-lane rows selected by ROWS (bit r = row r of the wave) only; the other rows keep their value:
-// the row-conditional rotates of l2g in ONE instruction per dword (DPP row_mask) instead of a permute plus a select
-template <int CTRL, int ROWS> __device__ inline int dpp_rows(int v) { CK_EXEC_FULL(2); return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xF, false); }
-template <int CTRL, int ROWS> __device__ inline float dpp_rows(float v) { return __int_as_float(dpp_rows<CTRL, ROWS>(__float_as_int(v))); }
-template <int CTRL, int ROWS> __device__ inline double dpp_rows(double v) {
-#if defined(__AMDGCN__) || defined(MPCQ_EMU_BUILD)
-  CK_EXEC_FULL(2);
-  const long long x = __builtin_bit_cast(long long, v);
-  return __builtin_bit_cast(double, (long long)__builtin_amdgcn_update_dpp(x, x, CTRL, ROWS, 0xF, false));
-#else
-  return __hiloint2double(dpp_rows<CTRL, ROWS>(__double2hiint(v)), dpp_rows<CTRL, ROWS>(__double2loint(v)));
-#endif
+// DPP permutation taken by the 16-lane rows selected by ROWS (bit r = row r of the wave) only: permute + select.  (The one-instruction
+// form -- DPP row_mask with the old value tied to the source -- was 0.6 % faster and was dropped: with it the free-running
+// instance of shape (20, 20) stopped reproducing the lockstep launches bit for bit, tests/test_gpu_parity.py::test_config2_full_size,
+// although every such instruction was emitted in place)
+template <int CTRL, int ROWS, typename T> __device__ inline T dpp_rows(T v, int h) {   // h = lane >> 4
+  const T r = dpp<CTRL>(v);
+  return ((ROWS >> h) & 1) ? r : v;
 }
 // sum over the four 16-lane rows (lanes c, c+16, c+32, c+48), result on every lane: after v_permlane16_swap(v, v) the two
 // outputs hold rows (0,0,2,2) and (1,1,3,3), after v_permlane32_swap rows (0,1,0,1) and (2,3,2,3) -- their sum is the
@@ -448,14 +443,13 @@ template <typename TQ> __device__ inline int RI(int s, int h) { return sizeof(TQ
 // h holds x[RI(s,h)], s = 0..3) without LDS: rotate row h left by U*h lanes (two conditional row_ror; U = 1 for the f64 slot
 // map h + 4s, 4 for the f32 map 4h + s), then row_newbcast of the lane that now holds the slot.
 template <typename TQ> __device__ inline void l2g(TQ x, int h, TQ (&v)[4]) {
-  (void)h;
   if (sizeof(TQ) == 8) {
-    x = dpp_rows<0x12F, 0xA>(x);            // rows 1, 3: row_ror:15 -> lane c <- lane c + 1
-    x = dpp_rows<0x12E, 0xC>(x);            // rows 2, 3: row_ror:14 -> lane c <- lane c + 2
+    x = dpp_rows<0x12F, 0xA>(x, h);            // rows 1, 3: row_ror:15 -> lane c <- lane c + 1
+    x = dpp_rows<0x12E, 0xC>(x, h);         // rows 2, 3: row_ror:14 -> lane c <- lane c + 2
     v[0] = dpp<0x150>(x); v[1] = dpp<0x154>(x); v[2] = dpp<0x158>(x); v[3] = dpp<0x15C>(x);   // row_newbcast:0,4,8,12
   } else {
-    x = dpp_rows<0x12C, 0xA>(x);            // rows 1, 3: row_ror:12 -> lane c <- lane c + 4
-    x = dpp_rows<0x128, 0xC>(x);            // rows 2, 3: row_ror:8  -> lane c <- lane c + 8
+    x = dpp_rows<0x12C, 0xA>(x, h);         // rows 1, 3: row_ror:12 -> lane c <- lane c + 4
+    x = dpp_rows<0x128, 0xC>(x, h);         // rows 2, 3: row_ror:8  -> lane c <- lane c + 8
     v[0] = dpp<0x150>(x); v[1] = dpp<0x151>(x); v[2] = dpp<0x152>(x); v[3] = dpp<0x153>(x);   // row_newbcast:0..3
   }
 }
@@ -999,8 +993,8 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, con
       const TQ t = hsum((qa[0][0] * pv[0] + qa[0][1] * pv[1]) + (qa[0][2] * pv[2] + qa[0][3] * pv[3]));   // (AB''^T p)[c]
       const TQ gt = t + rvc;                                   // gt_j = rho_j + (B^T p)_j on lane column 10 + j
       // row h needs gt_h on every lane: rotate row h left by h lanes, broadcast lane 10
-      TQ r = dpp_rows<0x12F, 0xA>(gt);
-      r = dpp_rows<0x12E, 0xC>(r);
+      TQ r = dpp_rows<0x12F, 0xA>(gt, h);
+      r = dpp_rows<0x12E, 0xC>(r, h);
       const TQ gh = dpp<0x15A>(r);
       pc = (arow ? t : (prow ? pc : TQ(0))) + hsum(kk * gh);   // p_i = A^T p_{i+1} + K^T gt (pinned rows of K are 0)
       TQ g[4];

@@ -15,21 +15,26 @@
 #define MPCQ_CAT3(a, b, c) a##b##_##c
 #define MPCQ_SPEC_NAME(prefix, n, nb) MPCQ_CAT3(prefix, n, nb)
 
+// LOCKSTEP instances only (one launch per control period).  The free-running launches (mpcq_sim_run) use the any-shape instance
+// of mpcq_api.hip for every shape: the shape-specialised free-running kernels (420-430 registers, ~430 SGPR spills at -O3 with the
+// unrolled stage loops) gave code-generation-dependent results and, for shape (20, 20), a device fault in round 3, while the same
+// source passes every index / EXEC check of the checked build and the any-shape instance reproduces the lockstep launches bit
+// for bit in every configuration tried (tests/test_gpu_parity.py::test_free_running_equals_lockstep_every_instance).
+
 namespace mpcq {
 
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
 
-template <typename T, bool RUN> static StepFn<T> pick(bool gab) {
+template <typename T> static StepFn<T> pick(bool gab) {
 #ifdef MPCQ_RESOURCE_PROBE   // tools/kernel_resources.sh: only the lockstep instance with the stage records in global memory
-  if (gab && !RUN && sizeof(T) == 8) return (StepFn<T>)&step_kernel<Cfg<double, true, MPCQ_SPEC_N, MPCQ_SPEC_NB, false>>;
+  if (gab && sizeof(T) == 8) return (StepFn<T>)&step_kernel<Cfg<double, true, MPCQ_SPEC_N, MPCQ_SPEC_NB, false>>;
   return nullptr;
 #else
-  return gab ? &step_kernel<Cfg<T, true, MPCQ_SPEC_N, MPCQ_SPEC_NB, RUN>> : &step_kernel<Cfg<T, false, MPCQ_SPEC_N, MPCQ_SPEC_NB, RUN>>;
+  return gab ? &step_kernel<Cfg<T, true, MPCQ_SPEC_N, MPCQ_SPEC_NB, false>> : &step_kernel<Cfg<T, false, MPCQ_SPEC_N, MPCQ_SPEC_NB, false>>;
 #endif
 }
 
-// run = the free-running closed-loop variant (mpcq_sim_run)
-StepFn<double> MPCQ_SPEC_NAME(spec_step_f64_, MPCQ_SPEC_N, MPCQ_SPEC_NB)(bool gab, bool run) { return run ? pick<double, true>(gab) : pick<double, false>(gab); }
-StepFn<float> MPCQ_SPEC_NAME(spec_step_f32_, MPCQ_SPEC_N, MPCQ_SPEC_NB)(bool gab, bool run) { return run ? pick<float, true>(gab) : pick<float, false>(gab); }
+StepFn<double> MPCQ_SPEC_NAME(spec_lock_f64_, MPCQ_SPEC_N, MPCQ_SPEC_NB)(bool gab) { return pick<double>(gab); }
+StepFn<float> MPCQ_SPEC_NAME(spec_lock_f32_, MPCQ_SPEC_N, MPCQ_SPEC_NB)(bool gab) { return pick<float>(gab); }
 
 }  // namespace mpcq

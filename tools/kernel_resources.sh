@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/mpc_quad_ros_amd/csrc
 TMP=$(mktemp -d)
 if [ "$UNIT" = spec ]; then OPT="-O3 -DMPCQ_UNROLL_FACTOR=2 -DMPCQ_UNROLL_SWEEP=10"; F=mpcq_spec.hip; else OPT="-O2"; F=mpcq_api.hip; fi
-/opt/rocm/bin/hipcc -fno-strict-aliasing -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 $OPT "$@" --cuda-device-only -c -o $TMP/dev.o $SRC/$F
+/opt/rocm/bin/hipcc -fno-strict-aliasing -std=c++17 --offload-arch=gfx950 ${VGPRFORM--mllvm -amdgpu-mfma-vgpr-form=1} $OPT "$@" --cuda-device-only -c -o $TMP/dev.o $SRC/$F
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$TMP/dev.o --output=$TMP/dev.co --unbundle
 LLVM=/opt/rocm/lib/llvm/bin
 python3 - "$TMP/dev.co" <<'PY'
