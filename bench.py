@@ -164,28 +164,45 @@ def parity_on_workload(dump, refs, N, nb, device, quads=64, periods=30, free_run
     return out
 
 
-def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps):
+def lockstep_leg(e, n_sub, warmup, steps, dist=None):
+    """Warm-up, then `steps` lockstep periods timed between two barriers (stream synchronised on both sides, plus the host
+    group's barrier under WORLD_SIZE > 1).  Returns (seconds between the barriers, seconds until this rank's own stream was
+    idle, mean step-kernel launch time by HIP events)."""
+    def barrier():
+        e.synchronize()                      # hipStreamSynchronize on the engine's stream (the only one used)
+        t = time.perf_counter()
+        if dist is not None:
+            dist.barrier()
+        return t
+    e.sim_steps(warmup, n_sub, 5e-3)
+    barrier()
+    t0 = time.perf_counter()
+    e.sim_steps(steps, n_sub, 5e-3)          # K fused steps + plant, back-to-back on one stream
+    t_own = barrier()
+    t1 = time.perf_counter()
+    kt, kl = e.get_kernel_time()             # HIP events around the step-kernel launches (all of them when steps <= 50, else every 4th)
+    return t1 - t0, t_own - t0, kt / max(kl, 1)
+
+
+def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps, dist=None, keep=False):
     """One of the other BASELINE configurations as a short lockstep leg (same workload family, pre-rolled): throughput only;
     their parity is covered by the GPU tests."""
     e, _cfg = make_engine(B, N, nb, prec, device, 0, 0, refs=(np.ascontiguousarray(refs[0][:B]), np.ascontiguousarray(refs[1][:B])))
     n_sub = e.plant_substeps(0.01, 5e-3)
     e.sim_run(preroll, n_sub, 5e-3)
-    e.sim_steps(warmup, n_sub, 5e-3)
-    e.lib.mpcq_synchronize(e.h)
-    t0 = time.perf_counter()
-    e.sim_steps(steps, n_sub, 5e-3)
-    e.lib.mpcq_synchronize(e.h)
-    t1 = time.perf_counter()
-    kt, kl = e.get_kernel_time()
+    dt, dt_own, k_avg = lockstep_leg(e, n_sub, warmup, steps, dist)
     its, status = e.get_qp_iter(), e.get_status()
     st = e.get_tracking_stats()
+    out = {"config": name, "value": B * steps / dt_own, "unit": "control steps/s", "dtype": "f64" if prec == PRECISION_F64 else "f32",
+           "batch": B, "horizon_nodes": N, "rgp_basis": nb, "steps": steps, "warmup": warmup, "preroll_periods": preroll,
+           "ms_per_step": 1e3 * dt_own / steps, "kernel_avg_ms": 1e3 * k_avg,
+           "algorithmic_gbs": algorithmic_bytes(N, nb, 8 if prec == PRECISION_F64 else 4) * B / k_avg / 1e9,
+           "mean_qp_passes": float(qp_passes(its).mean()), "failed": int(((status & 7) != 0).sum()),
+           "rms_pos_m": float(np.sqrt(st[0] / (3 * max(st[2], 1))))}
+    if keep:
+        return out, e, dt
     e.close()
-    return {"config": name, "value": B * steps / (t1 - t0), "unit": "control steps/s", "dtype": "f64" if prec == PRECISION_F64 else "f32",
-            "batch": B, "horizon_nodes": N, "rgp_basis": nb, "steps": steps, "warmup": warmup, "preroll_periods": preroll,
-            "ms_per_step": 1e3 * (t1 - t0) / steps, "kernel_avg_ms": 1e3 * kt / max(kl, 1),
-            "algorithmic_gbs": algorithmic_bytes(N, nb, 8 if prec == PRECISION_F64 else 4) * B / (kt / max(kl, 1)) / 1e9,
-            "mean_qp_passes": float(qp_passes(its).mean()), "failed": int(((status & 7) != 0).sum()),
-            "rms_pos_m": float(np.sqrt(st[0] / (3 * max(st[2], 1))))}
+    return out
 
 
 def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None, periods=1000, refs=None):
@@ -241,9 +258,13 @@ def cpu_baseline(N, nb, seed, budget_s=18.0, refs=None, start=None):
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = logical
-    sweep = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, phys, logical) if 1 <= t <= min(logical, affinity)})
+    # team sizes up to the CPUs this container may actually use (cgroup quota, affinity), one step beyond (2x) to show the
+    # plateau; a third of the budget goes to the sweep, the rest to a longer sample at the best team size
+    usable = int(min(logical, affinity, np.ceil(quota) if quota else logical))
+    sweep = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, usable, 2 * usable) if 1 <= t <= min(2 * usable, logical, affinity)})
     runs = []
-    for threads in sweep:
+
+    def sample(threads, seconds, max_steps):
         B = max(32, 4 * threads)
         cfg = EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb),
                            theta=[1.0, 0.1, 0.1], dt_pred=0.01)
@@ -264,18 +285,26 @@ def cpu_baseline(N, nb, seed, budget_s=18.0, refs=None, start=None):
             w, _ = o.step(x)
             x = o.plant_control_period(x, w, 0.01, 5e-3)[0]
         steps, t_step = 0, 0.0
-        t_end = time.perf_counter() + budget_s / len(sweep)
-        while (time.perf_counter() < t_end or steps < 3) and steps < 400:
+        t_end = time.perf_counter() + seconds
+        while (time.perf_counter() < t_end or steps < 3) and steps < max_steps:
             t0 = time.perf_counter()
             w, _ = o.step(x)
             t_step += time.perf_counter() - t0
             x = o.plant_control_period(x, w, 0.01, 5e-3)[0]
             steps += 1
-        runs.append({"threads": threads, "quads": B, "steps": steps, "steps_per_s": B * steps / t_step,
-                     "us_per_step_per_thread": 1e6 * t_step * threads / (B * steps)})
         o.set_threads(logical)
         o.close()
-    best = max(runs, key=lambda r: r["steps_per_s"])
+        return {"threads": threads, "quads": B, "steps": steps, "steps_per_s": B * steps / t_step,
+                "us_per_step_per_thread": 1e6 * t_step * threads / (B * steps)}, from_start
+
+    for threads in sweep:
+        r, from_start = sample(threads, budget_s / 3 / len(sweep), 400)
+        runs.append(r)
+    best_threads = max(runs, key=lambda r: r["steps_per_s"])["threads"]
+    long_run, from_start = sample(best_threads, 2 * budget_s / 3, 3000)
+    long_run["long_sample"] = True
+    runs.append(long_run)
+    best = long_run      # the longer sample at the best team size of the sweep is the reported figure
     return {"value": best["steps_per_s"], "unit": "control steps/s", "cores": best["threads"], "kind": "port",
             "sample": f"{best['quads']} quads x {best['steps']} closed-loop steps "
                       + ("continued from the end state of the GPU run (same flights, same regime)" if from_start else "from hover")
@@ -308,16 +337,60 @@ def call_with_timeout(fn, seconds=90.0):
     return True, box.get("r")
 
 
+SWARM_PER_RANK = 8192          # BASELINE configs[3]: 65 536 quadrotors over 8 GPUs
+SWARM_WARM, SWARM_STEPS = 5, 20
+
+
+def reduce_stats(e, dist, world, use_rccl):
+    """The path's only collective: the 5-number tracking statistic, all-reduced by RCCL inside libmpcq.so (SUM of slots
+    0,1,2,4, MAX of slot 3); over the host group when RCCL is not available (and the line says so)."""
+    how, hung, stats = ("rccl" if use_rccl else "gloo"), False, None
+    if world == 1:
+        return e.get_tracking_stats(), "single", False
+    import torch
+    if use_rccl:
+        oks, rs = call_with_timeout(e.allreduce_tracking_stats)
+        flag = torch.tensor([1 if oks else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            stats = rs
+        else:
+            hung = rs == "timeout"
+            how = "gloo (RCCL all-reduce failed)"
+    if stats is None:
+        st = e.get_tracking_stats()
+        ssum = torch.tensor([st[0], st[1], st[2], 0.0, st[4]], dtype=torch.float64)
+        smax = torch.tensor([st[3]], dtype=torch.float64)
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+        stats = ssum.numpy().copy()
+        stats[3] = float(smax[0])
+    return stats, how, hung
+
+
+def per_rank_summary(dist, world, mine):
+    """Every rank's own timing of a leg (dict of floats), gathered over the host group: {key: {min, mean, max}} + the list."""
+    rows = [mine]
+    if world > 1:
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+    out = {k: {"min": min(r[k] for r in rows), "mean": sum(r[k] for r in rows) / len(rows), "max": max(r[k] for r in rows)} for k in mine}
+    out["ranks"] = rows
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0,
-                    help="quadrotors per GPU; default: 1024 on one GPU (BASELINE configs[1]), 8192 per rank under WORLD_SIZE > 1 "
-                         "(configs[3]: 65 536 quadrotors over 8 GPUs)")
-    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations")
+                    help="quadrotors per GPU; default 1024 (BASELINE configs[1]) at EVERY world size: the `value` series over N GPUs is a "
+                         "weak-scaling series.  configs[3] (8192 per GPU, 65 536 over 8) rides in every line as the `swarm` leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations (and the swarm leg)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check on the workload")
+    ap.add_argument("--steady", type=int, default=200, help="control periods of the steady-state leg that follows the timed region on the same engine "
+                                                            "(one GPU only; 0: skip it and the other-seeds legs)")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--nb", type=int, default=10)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
@@ -329,12 +402,16 @@ def main():
                     help="un-timed control periods before the warm-up, the same for every --steps/--warmup: the timed region "
                          "starts in the stationary mix of a swarm in continuous operation (each quadrotor chains min-snap flights of "
                          "2.6 - 9.8 s; after 6 s their phases are spread), whatever --steps and --warmup are")
-    ap.add_argument("--strict-rccl", action="store_true", help="exit non-zero when WORLD_SIZE > 1 and the RCCL reduction did not run")
+    ap.add_argument("--strict-rccl", dest="strict_rccl", action="store_true", default=None,
+                    help="exit non-zero when WORLD_SIZE > 1 and the RCCL reduction did not run (the default under WORLD_SIZE > 1)")
+    ap.add_argument("--no-strict-rccl", dest="strict_rccl", action="store_false",
+                    help="accept a reduction over the host group when RCCL cannot be brought up (the line says which one ran)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("MPCQ_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # MPCQ_BENCH_DEVICE: testing aid (several ranks on one GPU)
+    strict = (world > 1) if args.strict_rccl is None else args.strict_rccl
     dist = None
     if world > 1:
         import torch.distributed as dist  # host-side rendezvous only (barrier, max, id broadcast)
@@ -342,26 +419,32 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"# note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
 
-    B = args.batch if args.batch > 0 else (1024 if world == 1 else 8192)
+    B = args.batch if args.batch > 0 else 1024
     N, nb = args.horizon, args.nb
     prec = PRECISION_F64 if args.precision == "f64" else PRECISION_F32
     itemsize = 8 if prec == PRECISION_F64 else 4
-    periods = args.preroll + args.warmup + args.steps
+    STEADY = args.steady if world == 1 else 0          # further periods on the same engine behind the timed region
+    periods = args.preroll + args.warmup + args.steps + STEADY
+    headline = (B, N, nb) == (1024, 20, 10)
+    legs = world == 1 and not args.no_configs and headline
+    swarm = not args.no_configs and headline           # configs[3]: 8192 quadrotors on every rank, at every world size
+    seeds_alt = [1, 2, 3] if (world == 1 and headline and STEADY > 0) else []
     t_gen = time.perf_counter()
     refs = workload(args.seed, rank * B, B, periods)      # host-side generation (worker processes) before the GPU is touched
-    legs = world == 1 and not args.no_configs and (B, N, nb) == (1024, 20, 10)
     CFG_PRE, CFG_WARM, CFG_STEPS = 300, 5, 20
     refs_cfg = workload(args.seed, 0, 8192, CFG_PRE + CFG_WARM + CFG_STEPS) if legs else None   # shared by the legs (150 rows >= N skip)
+    refs_swarm = workload(args.seed, rank * SWARM_PER_RANK, SWARM_PER_RANK, args.preroll + SWARM_WARM + SWARM_STEPS) if swarm else None
+    refs_seeds = {sd: workload(sd, 0, B, args.preroll + 10 + 50) for sd in seeds_alt}
     t_gen = time.perf_counter() - t_gen
     e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods, refs=refs)
     stats_reduce = "single"
     rccl_hung = False
+    uid_bytes = None
     if world > 1:
         # the only collective of the path: RCCL all-reduce of the 5-number swarm statistic inside libmpcq.so.
         # If RCCL cannot be brought up on this node the statistic is reduced over the host group instead
-        # (and the bench line says so); the timed region has no collective either way.
+        # (and the bench line says so; with --strict-rccl, the default here, the run then fails); the timed region has no collective.
         stats_reduce = "rccl"
-        rccl_hung = False
         okid, rid = call_with_timeout(lambda: e.comm_unique_id() if rank == 0 else None)
         uid = [rid if okid else f"ERR {rid}"]
         dist.broadcast_object_list(uid, src=0)
@@ -380,23 +463,12 @@ def main():
         if int(flag[0]) == 0:
             stats_reduce = "gloo (RCCL unavailable)"
 
-    def barrier():
-        e.lib.mpcq_synchronize(e.h)          # hipStreamSynchronize on the engine's stream (the only one used)
-        if dist is not None:
-            dist.barrier()
-
     n_sub = e.plant_substeps(0.01, 5e-3)     # 100 Hz odometry = 2 plant substeps of 5 ms (the reference's float-accumulated loop)
     if args.preroll > 0:
         # one persistent launch (every quadrotor advances through the pre-roll on its own; bit-identical to per-period
         # launches): the lockstep kernel's launches seen by a profiler are then exactly warm-up + timed steps
         e.sim_run(args.preroll, n_sub, 5e-3)
-    e.sim_steps(args.warmup, n_sub, 5e-3)
-    barrier()
-    t0 = time.perf_counter()
-    e.sim_steps(args.steps, n_sub, 5e-3)     # K fused steps + plant, back-to-back on one stream
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed, own_elapsed, k_avg_own = lockstep_leg(e, n_sub, args.warmup, args.steps, dist)   # W untimed launches, barrier, K timed launches, barrier
     start = None
     if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_parity):   # where the CPU legs continue from
         start = dump_engine(e)
@@ -409,27 +481,52 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    stats = None
-    if world > 1 and stats_reduce == "rccl":
-        oks, rs = call_with_timeout(e.allreduce_tracking_stats)
-        import torch
-        flag = torch.tensor([1 if oks else 0], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
-            stats = rs
-        else:
-            rccl_hung = rccl_hung or rs == "timeout"
-            stats_reduce = "gloo (RCCL all-reduce failed)"
-    if stats is None:
-        stats = e.get_tracking_stats()
-        if world > 1:
+    # every rank's own clock around its K launches (the barrier that ends the region is included in `elapsed`, not here)
+    ranks = per_rank_summary(dist, world, {"ms_per_step": 1e3 * own_elapsed / args.steps, "kernel_avg_ms": 1e3 * k_avg_own,
+                                           "steps_per_s": B * args.steps / own_elapsed})
+    stats, stats_reduce2, hung2 = reduce_stats(e, dist, world, stats_reduce == "rccl")
+    if world > 1:
+        stats_reduce, rccl_hung = (stats_reduce2 if stats_reduce == "rccl" else stats_reduce), rccl_hung or hung2
+    # ---- steady state: the driver's --steps 20 window is 6 ms of a workload whose launch time follows the number of saturated
+    #      quadrotors in flight; 200 further periods on the same engine give the representative figure
+    steady = None
+    if STEADY:
+        dt_s, _own, k_s = lockstep_leg(e, n_sub, 0, STEADY)
+        steady = {"value": B * STEADY / dt_s, "unit": "control steps/s", "steps": STEADY, "ms_per_step": 1e3 * dt_s / STEADY, "kernel_avg_ms": 1e3 * k_s,
+                  "note": f"the {STEADY} control periods that follow the timed region, same engine: the representative lockstep rate of this workload "
+                          "(`value` above is the driver's window; its launches hold more or fewer saturated quadrotors by chance)"}
+
+    # ---- configs[3]-shaped leg on every rank: 8192 quadrotors per GPU (65 536 over 8), same pre-roll as the headline
+    swarm_out = None
+    if swarm:
+        leg, es, agg_dt = config_leg(f"configs[3] per rank: batch {SWARM_PER_RANK} of {SWARM_PER_RANK * 8}, N=20, RGP 10 basis pts", refs_swarm, SWARM_PER_RANK, 20, 10,
+                                     PRECISION_F64, local_rank, args.preroll, SWARM_WARM, SWARM_STEPS, dist=dist, keep=True)
+        if dist is not None:      # between the barriers, MAX over ranks (as the headline)
             import torch
-            ssum = torch.tensor([stats[0], stats[1], stats[2], 0.0, stats[4]], dtype=torch.float64)
-            smax = torch.tensor([stats[3]], dtype=torch.float64)
-            dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
-            dist.all_reduce(smax, op=dist.ReduceOp.MAX)
-            stats = ssum.numpy().copy()
-            stats[3] = float(smax[0])
+            t = torch.tensor([agg_dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            agg_dt = float(t[0])
+        sranks = per_rank_summary(dist, world, {"ms_per_step": leg["ms_per_step"], "kernel_avg_ms": leg["kernel_avg_ms"], "steps_per_s": leg["value"]})
+        if world > 1 and stats_reduce == "rccl":      # the swarm statistic of THIS leg through RCCL as well
+            okid, rid = call_with_timeout(lambda: es.comm_unique_id() if rank == 0 else None)
+            uid = [rid if okid else None]
+            dist.broadcast_object_list(uid, src=0)
+            okc = isinstance(uid[0], (bytes, bytearray)) and call_with_timeout(lambda: es.comm_init(rank, world, uid[0]))[0]
+            import torch
+            flag = torch.tensor([1 if okc else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            sstats, show, hung3 = reduce_stats(es, dist, world, int(flag[0]) == 1)
+            rccl_hung = rccl_hung or hung3
+        else:
+            sstats, show, _ = reduce_stats(es, dist, world, False)
+        es.close()
+        best = sranks["steps_per_s"]["max"]
+        swarm_out = dict(leg)
+        swarm_out.update({"config": f"BASELINE configs[3]: swarm of {SWARM_PER_RANK * world} quadrotors, {SWARM_PER_RANK} per GPU over {world} GPU(s)"
+                                    + (" (= the per-rank shard of the 65 536-quadrotor swarm)" if world == 1 else ""),
+                          "value": SWARM_PER_RANK * world * SWARM_STEPS / agg_dt, "n_gpus": world, "global_batch": SWARM_PER_RANK * world,
+                          "ms_per_step": 1e3 * agg_dt / SWARM_STEPS, "per_rank": sranks, "efficiency_vs_best_rank": SWARM_PER_RANK * world * SWARM_STEPS / agg_dt / (world * best),
+                          "stats_reduce": show, "rms_pos_m": float(np.sqrt(sstats[0] / (3 * max(sstats[2], 1)))), "tracking_steps": float(sstats[2])})
 
     if rank == 0:
         total_steps = B * world * args.steps
@@ -443,17 +540,17 @@ def main():
             "value": value, "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1]: batch {B} hummingbird quadrotors" if world == 1 else
-                                    f"BASELINE configs[3]: swarm of {B * world} hummingbird quadrotors sharded over {world} GPUs ({B} per GPU)")
+            "config": {"workload": f"BASELINE configs[1] per GPU: batch {B} hummingbird quadrotors" + (f" on each of {world} GPUs ({B * world} in total)" if world > 1 else "")
                                    + f", N={N}, RGP {nb} basis pts/axis, closed loop with on-device drag plant, continuous operation on seeded "
                                      "random-waypoint min-snap flights (3 waypoints each, v_max=a_max=12)",
                        "batch_per_gpu": B, "global_batch": B * world, "horizon_nodes": N, "rgp_basis": nb, "preroll_periods": args.preroll,
                        "parallelism": f"shard{world}" if world > 1 else "single", "threads_per_quad": 64,
                        "stats_reduce": stats_reduce, "rccl_ok": world == 1 or stats_reduce == "rccl",
-                       "scaling_note": ("weak scaling at 8192 quadrotors per GPU for every N > 1 (N = 8 is BASELINE configs[3], 65 536 quadrotors); the N = 1 "
-                                        "line is configs[1] (1024 quadrotors, one wave per SIMD) -- the one-GPU reference point for the N > 1 lines is the "
-                                        "'configs[3] per rank' entry under `configs` of the N = 1 line") if world > 1 else
-                                       "one GPU: BASELINE configs[1]; under WORLD_SIZE > 1 the default is 8192 quadrotors per GPU (configs[3])"},
+                       "scaling_note": f"weak scaling: {B} quadrotors per GPU at every world size, sharded by global index, no collective on the data path; "
+                                       "BASELINE configs[3] (8192 per GPU, 65 536 over 8 GPUs) is the `swarm` object of every line, at the same "
+                                       "per-GPU batch for every world size as well"},
+            "per_rank": ranks,
+            "efficiency_vs_best_rank": value / (world * ranks["steps_per_s"]["max"]),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": f"mpcq::step_kernel<{'double' if prec == PRECISION_F64 else 'float'}>",
@@ -472,6 +569,10 @@ def main():
             "tracking": {"rms_pos_m": float(np.sqrt(stats[0] / (3 * max(stats[2], 1)))), "steps": float(stats[2]),
                          "max_pos_err_m": float(np.sqrt(stats[3])), "failed_instances": float(stats[4])},
         }
+        if steady is not None:
+            out["steady_state"] = steady
+        if swarm_out is not None:
+            out["swarm"] = swarm_out
         # HBM bytes per launch from rocprofv3 --pmc passes (profiles/README.md): attached only when the profile was taken on
         # THIS build (source hash) with THIS command line; otherwise null -- a number from another build is not this run's traffic.
         import glob
@@ -490,6 +591,16 @@ def main():
                 out["roofline"]["traffic_source"] = {"file": os.path.basename(f), "source_sha16": sha, "command": t.get("command"),
                                                      "commit": t.get("commit")}
                 out["roofline"]["traffic_note"] = t.get("note", "")
+        if seeds_alt:
+            # the same workload from other seeds (the solver heuristics were tuned on the default one): 50 periods each
+            out["seeds"] = []
+            for sd in seeds_alt:
+                es, _ = make_engine(B, N, nb, prec, local_rank, 0, sd, refs=refs_seeds[sd])
+                es.sim_run(args.preroll, n_sub, 5e-3)
+                dt_s, _own, k_s = lockstep_leg(es, n_sub, 10, 50)
+                st_s = es.get_status()
+                out["seeds"].append({"seed": sd, "value": B * 50 / dt_s, "steps": 50, "warmup": 10, "kernel_avg_ms": 1e3 * k_s, "failed": int(((st_s & 7) != 0).sum())})
+                es.close()
         if world == 1 and not args.no_alt:
             # Same K periods as ONE launch in which every quadrotor runs through its periods without waiting for the
             # slowest member of the batch (mpcq_sim_run): the lockstep figure above is what a controller fed by live
@@ -498,43 +609,44 @@ def main():
             e.close()
             e3, _ = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods, refs=refs)
             e3.sim_run(args.preroll + args.warmup, n_sub, 5e-3)
-            e3.lib.mpcq_synchronize(e3.h)
+            e3.synchronize()
             ta = time.perf_counter()
-            e3.sim_run(args.steps, n_sub, 5e-3)
-            e3.lib.mpcq_synchronize(e3.h)
+            e3.sim_run(args.steps + STEADY, n_sub, 5e-3)
+            e3.synchronize()
             tb = time.perf_counter()
             k3, _l3 = e3.get_kernel_time()
             x_run, w_run = e3.sim_get_state()
-            out["free_running"] = {"value": B * args.steps / (tb - ta), "unit": "control steps/s", "dtype": args.precision,
-                                   "ms_per_step": 1e3 * (tb - ta) / args.steps, "kernel_ms_per_step": 1e3 * k3 / args.steps,
+            out["free_running"] = {"value": B * (args.steps + STEADY) / (tb - ta), "unit": "control steps/s", "dtype": args.precision, "steps": args.steps + STEADY,
+                                   "ms_per_step": 1e3 * (tb - ta) / (args.steps + STEADY), "kernel_ms_per_step": 1e3 * k3 / (args.steps + STEADY),
                                    "launches": 1, "bitwise_equal_to_lockstep": bool(np.array_equal(x_run, x_lock) and np.array_equal(w_run, w_lock)),
-                                   "note": "one persistent launch, each workgroup advances its quadrotor through all K control periods "
+                                   "note": "one persistent launch over the timed AND the steady-state periods, each workgroup advances its quadrotor through all of them "
                                            "(step + plant) on its own; identical arithmetic and results, no per-period wait for the "
                                            "slowest instance of the batch"}
             e3.close()
             alt = "f32" if args.precision == "f64" else "f64"
             e2, _ = make_engine(B, N, nb, PRECISION_F32 if alt == "f32" else PRECISION_F64, local_rank, 0, args.seed, periods=periods, refs=refs)
             e2.sim_steps(args.preroll + args.warmup, n_sub, 5e-3)
-            e2.lib.mpcq_synchronize(e2.h)
+            e2.synchronize()
             ta = time.perf_counter()
             e2.sim_steps(args.steps, n_sub, 5e-3)
-            e2.lib.mpcq_synchronize(e2.h)
+            e2.synchronize()
             tb = time.perf_counter()
             k2, l2 = e2.get_kernel_time()
             st2 = e2.get_status()
             out["experimental_f32" if alt == "f32" else "alt_precision"] = {"dtype": alt, "value": B * args.steps / (tb - ta), "unit": "control steps/s",
                                     "kernel_avg_ms": 1e3 * k2 / max(l2, 1), "failed": int(((st2 & 7) != 0).sum()),
                                     "low_accuracy_last_step": int((st2 == 8).sum()),
-                                    "note": "same workload with the QP arithmetic in the other precision.  f32 is an EXPERIMENTAL mode (include/mpcq.h): "
-                                            "it meets the 1e-4 control budget on solves that succeed from their warm start; solves that went through "
-                                            "the interior point are reported per instance as MPCQ_SOLVE_LOW_ACCURACY (counted here for the last step).  "
+                                    "note": "same workload with the QP arithmetic in the other precision.  f32 is an EXPERIMENTAL mode (include/mpcq.h states the "
+                                            "measured bounds): solves that went through the interior point or started cold are reported per instance as "
+                                            "MPCQ_SOLVE_LOW_ACCURACY (counted here for the last step).  "
                                             "f64 is the reference's own arithmetic (<= 1e-7 vs the fp64 oracle)"}
             e2.close()
         if legs:
             # the other BASELINE configurations, reachable from the driver's command: short lockstep legs after the headline
             out["configs"] = [
                 config_leg("configs[2]: batch 8192, N=20, RGP 20 basis pts", refs_cfg, 8192, 20, 20, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
-                config_leg("configs[3] per rank: batch 8192 of 65536, N=20, RGP 10 basis pts", refs_cfg, 8192, 20, 10, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
+                {k: v for k, v in swarm_out.items() if k not in ("per_rank", "efficiency_vs_best_rank", "n_gpus", "global_batch", "stats_reduce", "tracking_steps")}
+                | {"config": f"configs[3] per rank: batch {SWARM_PER_RANK} of {SWARM_PER_RANK * 8}, N=20, RGP 10 basis pts (the `swarm` leg of this line: same pre-roll as an N > 1 run)"},
                 config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
                 config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F32, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
             ]
@@ -547,11 +659,11 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-        if args.strict_rccl and not rccl_ok and not rccl_hung:
+        if strict and not rccl_ok and not rccl_hung:
             sys.exit(3)
         if rccl_hung:            # a thread is still blocked inside RCCL: skip the destructors
             sys.stdout.flush()
-            os._exit(3 if args.strict_rccl else 0)
+            os._exit(3 if strict else 0)
 
 
 if __name__ == "__main__":

@@ -66,7 +66,7 @@ typedef enum mpcq_status {
  * precision; validated by mpcq_create (MPCQ_ERR_INVALID outside the stated range).  The defaults were measured on two
  * workloads; results do not depend on them beyond rounding.  With MPCQ_TUNING=1 in the
  * environment, MPCQ_WARM_MAX, MPCQ_WARM_RETRY, MPCQ_FLIP_MAX, MPCQ_ABORT_PINS, MPCQ_ABORT_WRONG, MPCQ_POLISH_MAX,
- * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global, MPCQ_GENERIC=1 override
+ * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global, MPCQ_GENERIC=1, MPCQ_BLOCK_ORDER override
  * the corresponding field (measurement scripts only; without MPCQ_TUNING=1 the environment is not consulted). */
 typedef struct mpcq_tuning {
   int32_t warm_max;     /* passes of the warm active-set attempt, 1..64 (default 6 f64 / 12 f32) */
@@ -81,6 +81,10 @@ typedef struct mpcq_tuning {
   double ipm_mu0;       /* complementarity of the interior start in units of the gradient scale, [1e-12, 1] (default 1e-4) */
   double ipm_margin;    /* interior start: distance from the bounds in units of their width, (0, 0.5) (default 0.1) */
   double ipm_tol;       /* interior point -> active-set hand-over tolerance, [qp_tol, 1e-1] (default 1e-6 f64 / 1e-4 f32) */
+  /* ---- since 0.4 */
+  int32_t block_order;  /* launch order of a lockstep period: 0 automatic (quadrotors predicted expensive first when the batch exceeds
+                           what the device holds at once), 1 never (workgroup p = quadrotor p), 2 always.  Results do not depend on it. */
+  int32_t reserved0;    /* must be 0 */
 } mpcq_tuning;
 
 /* Engine configuration.  Replaces the constructor arguments of quad_optimizer
@@ -224,6 +228,10 @@ int mpcq_get_kernel_time_minmax(mpcq_engine* e, double* fastest_s, double* slowe
 /* diagnostic build only (libmpcq_prof.so, -DMPCQ_PROFILE): per-instance shader-cycle totals per phase of
  * the last step, out [B][16]; MPCQ_ERR_STATE in the product build. */
 int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out);
+/* The launch order of the last lockstep period, out [B]: workgroup p ran quadrotor out[p] (mpcq_tuning.block_order; the
+ * identity when no order is in use).  The reference solves one quadrotor per process (src/quad_opt.py:321-350) and has no
+ * counterpart; results do not depend on the order. */
+int mpcq_get_block_order(mpcq_engine* e, int32_t* out);
 
 /* ---- tracking statistic (src/Visualiser.py:787-789,809-811,918), summed over this engine's
  * instances since the last reset: out[0]=sum |e_pos|^2, out[1]=sum |e_vel|^2, out[2]=steps,

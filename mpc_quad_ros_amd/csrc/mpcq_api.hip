@@ -170,6 +170,7 @@ struct mpcq_engine {
   virtual int sim_get(double*, double*) = 0;
   virtual int stats(double*) = 0;
   virtual int get_prof(unsigned long long*) = 0;
+  virtual int get_order(int32_t*) = 0;
   virtual int get_command(double*, double*, double*) = 0;
   virtual int get_finished(int32_t*) = 0;
   virtual int get_chunk(double*) = 0;
@@ -195,15 +196,18 @@ struct EngineT : mpcq_engine {
   double* h_pin = nullptr;   // pinned staging of the host-buffer step: [x_meas B*13 | w B*4 | x_pred B*13]
   double *d_xin = nullptr, *d_uin = nullptr, *d_tmp = nullptr, *d_traj = nullptr, *d_xs = nullptr, *d_vb = nullptr, *d_ad = nullptr;
   int* d_tlen = nullptr;
+  int* d_order = nullptr;    // launch order of the lockstep periods (order_kernel); used when the batch exceeds what the device holds at once
+  bool use_order = false;
   double* d_cmd = nullptr;   // [B*8] rotor thrusts, collective thrust, body rates (mpcq_get_command); also the chunk read-back
   size_t cmd_elems = 0;
   std::vector<T> hbuf;
+  std::vector<int> hlen;
   std::vector<double> Kx;
 
   ~EngineT() override {
     DeviceGuard guard(cfg.device);
     void* ptrs[] = {st.chk, st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
-                    st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5};
+                    st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5, d_order};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     if (h_pin) (void)hipHostFree(h_pin);
@@ -261,6 +265,13 @@ struct EngineT : mpcq_engine {
     // overrides a field (measurement scripts).  How the defaults were measured: DESIGN.md section 3.3.
     const mpcq_tuning& tu = c.tune;
     const bool env = tuning_env = getenv("MPCQ_TUNING") && atoi(getenv("MPCQ_TUNING")) != 0;
+    if (!env) {   // advisor finding: a measurement script that forgets MPCQ_TUNING=1 would otherwise compare identical configurations
+      static const char* const knobs[] = {"MPCQ_WARM_MAX", "MPCQ_WARM_RETRY", "MPCQ_FLIP_MAX", "MPCQ_ABORT_PINS", "MPCQ_ABORT_WRONG", "MPCQ_POLISH_MAX", "MPCQ_PIN_RATIO",
+                                          "MPCQ_IPM_MU0", "MPCQ_IPM_MARGIN", "MPCQ_IPM_TOL", "MPCQ_STAGE_MEM", "MPCQ_GENERIC", "MPCQ_BLOCK_ORDER", "MPCQ_KEV_STRIDE"};
+      static bool warned = false;
+      for (const char* k : knobs)
+        if (!warned && getenv(k)) { fprintf(stderr, "mpcq: %s is set but MPCQ_TUNING=1 is not: the environment is ignored (use mpcq_config.tune)\n", k); warned = true; }
+    }
     auto ienv = [&](const char* name, int v) { const char* t = env ? getenv(name) : nullptr; return t ? atoi(t) : v; };
     auto fenv = [&](const char* name, double v) { const char* t = env ? getenv(name) : nullptr; return t ? atof(t) : v; };
     auto off = [](int v) { return v < 0 ? 0 : v; };   // -1 = "never": the kernel's encoding is 0 (flip_max: -1)
@@ -374,6 +385,15 @@ struct EngineT : mpcq_engine {
     L = gab ? Lg : Ll;
     lds_bytes = gab ? bg : bl;
     if ((rc = dalloc(st.stage, Bz * L.gtotal))) return rc;   // stage records (global placement) + multiplier rows
+    // Launch order of a lockstep period: a batch beyond what the device holds at once is a stream of workgroups that ends with
+    // its last one, so the quadrotors predicted to be expensive go first (mpcq::order_kernel in front of every step launch).
+    // A batch that is resident as a whole starts all at once: no order needed.  tune.block_order: 1 = never, 2 = always.
+    {
+      const size_t resident = (gab ? occ_g : occ_l) * (size_t)n_cu;
+      const int bo = ienv("MPCQ_BLOCK_ORDER", tu.block_order);
+      use_order = bo == 2 || (bo == 0 && (size_t)B > resident);
+      if (use_order && (rc = dalloc(d_order, Bz))) return rc;
+    }
     kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false>>;
     // free-running launches (mpcq_sim_run): the any-shape instance for every shape (mpcq_spec.hip says why)
     krun = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false, 0, -1, true>>;
@@ -455,7 +475,16 @@ struct EngineT : mpcq_engine {
     return 0;
   }
   int base_mode() const { return (cfg.flags & MPCQ_FLAG_STATIC_GP) ? mpcq::MODE_STATIC_GP : 0; }
-  void launch_period(const mpcq::DevState<T>& s, int mode) { hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode); }
+  void launch_period(const mpcq::DevState<T>& s, int mode) {
+    if (use_order) {   // (reads qp_iter of the previous period; a permutation by construction whatever qp_iter holds)
+      hipLaunchKernelGGL(mpcq::order_kernel, dim3(mpcq::ORD_CLASSES), dim3(mpcq::ORD_THREADS), mpcq::ORD_LDS, stream, (const int*)st.qp_iter, B, d_order);
+      mpcq::DevState<T> so = s;
+      so.order = d_order;
+      hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, so, mode);
+      return;
+    }
+    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode);
+  }
   int launch_step(int mode) {
     HIP_TRY(hipEventRecord(ev0, stream));
     launch_period(st, mode);
@@ -671,10 +700,22 @@ struct EngineT : mpcq_engine {
   }
   int set_solver_state(const int32_t* qp_iter, const double* stats4, const int32_t* finished) override {
     int rc;
+    if (qp_iter)   // decimal fields of include/mpcq.h: passes < 1000, three one-digit fields above
+      for (int b = 0; b < B; ++b)
+        if (qp_iter[b] < 0 || qp_iter[b] >= 1000000) return fail(MPCQ_ERR_INVALID, "mpcq_set_solver_state: qp_iter outside [0, 1e6)");
+    if (finished)
+      for (int b = 0; b < B; ++b)
+        if (finished[b] != 0 && finished[b] != 1) return fail(MPCQ_ERR_INVALID, "mpcq_set_solver_state: finished must be 0 or 1");
     if (qp_iter) HIP_TRY(hipMemcpyAsync(st.qp_iter, qp_iter, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     if (finished) HIP_TRY(hipMemcpyAsync(st.finished, finished, (size_t)B * sizeof(int), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (stats4 && (rc = h2d(st.stats, stats4, (size_t)B * 4))) return rc;
+    return 0;
+  }
+  int get_order(int32_t* out) override {   // the permutation the last lockstep launch used (identity when no order is in use)
+    if (!use_order) { for (int b = 0; b < B; ++b) out[b] = b; return 0; }
+    HIP_TRY(hipMemcpyAsync(out, d_order, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
   int get_prof(unsigned long long* out) override {
@@ -701,6 +742,20 @@ struct EngineT : mpcq_engine {
   int set_state(const double* X, const double* U, const double* mu, const double* C, const double* xpp, const int32_t* hp,
                 const int32_t* idx) override {
     int rc;
+    // a cursor outside its trajectory would make the step kernel read reference rows out of range (only the checked build
+    // would notice): refused here.  Without trajectories (explicit path) the cursor only counts periods: >= 0.
+    if (idx) {
+      if (have_traj) {
+        hlen.resize(B);
+        HIP_TRY(hipMemcpyAsync(hlen.data(), d_tlen, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+      }
+      for (int b = 0; b < B; ++b)
+        if (idx[b] < 0 || (have_traj && idx[b] > hlen[b])) return fail(MPCQ_ERR_INVALID, "mpcq_set_state: trajectory cursor outside [0, length]");
+    }
+    if (hp)
+      for (int b = 0; b < B; ++b)
+        if (hp[b] != 0 && hp[b] != 1) return fail(MPCQ_ERR_INVALID, "mpcq_set_state: has_prev must be 0 or 1");
     if (X && (rc = h2d(st.X, X, (size_t)B * (N + 1) * 13))) return rc;
     if (U && (rc = h2d(st.U, U, (size_t)B * N * 4))) return rc;
     if (mu && nb && (rc = h2q(st.mu, mu, (size_t)B * 3 * nb))) return rc;
@@ -720,9 +775,9 @@ extern "C" {
 
 const char* mpcq_last_error(void) { return g_err.c_str(); }
 #ifdef MPCQ_CHECKED
-const char* mpcq_version(void) { return "mpcq 0.3 (gfx950, CHECKED diagnostic build)"; }
+const char* mpcq_version(void) { return "mpcq 0.4 (gfx950, CHECKED diagnostic build)"; }
 #else
-const char* mpcq_version(void) { return "mpcq 0.3 (gfx950)"; }
+const char* mpcq_version(void) { return "mpcq 0.4 (gfx950)"; }
 #endif
 
 int mpcq_create(const mpcq_config* c, mpcq_engine** out) { return mpcq_create_sized(c, sizeof(mpcq_config), out); }
@@ -753,7 +808,7 @@ int mpcq_create_sized(const mpcq_config* c_in, uint64_t cfg_size, mpcq_engine** 
     auto frange = [](double v, double lo, double hi) { return v == 0 || (v >= lo && v <= hi); };   // NaN fails both
     if (!irange(t.warm_max, 1, 64, false) || !irange(t.warm_retry, 1, 64, false) || !irange(t.flip_max, 1, 512, true) ||
         !irange(t.abort_pins, 1, 512, true) || !irange(t.abort_wrong, 1, 512, true) || !irange(t.polish_max, 1, 64, true) ||
-        !irange(t.stage_mem, 1, 2, false) || !irange(t.generic_kernel, 1, 1, false))
+        !irange(t.stage_mem, 1, 2, false) || !irange(t.generic_kernel, 1, 1, false) || !irange(t.block_order, 1, 2, false) || t.reserved0 != 0)
       return fail(MPCQ_ERR_INVALID, "mpcq_config.tune: integer field out of range (see mpcq.h)");
     if (!frange(t.pin_ratio, 1e-300, 1e3) || !frange(t.ipm_mu0, 1e-12, 1.0) || !(t.ipm_margin == 0 || (t.ipm_margin > 0 && t.ipm_margin < 0.5)) ||
         !frange(t.ipm_tol, 1e-300, 1e-1))
@@ -841,6 +896,7 @@ int mpcq_get_kernel_time_minmax(mpcq_engine* e, double* mn, double* mx) { ENTER(
 int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]) { ENTER(e); return e->stats(out); }
 /* diagnostic build only: per-instance phase cycle totals of the last step, [B][16] */
 int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out) { ENTER(e); return e->get_prof(out); }
+int mpcq_get_block_order(mpcq_engine* e, int32_t* out) { ENTER(e); if (!out) return fail(MPCQ_ERR_INVALID, "null argument"); return e->get_order(out); }
 
 int mpcq_comm_unique_id(void* id128) {
   int rc = rccl_load();

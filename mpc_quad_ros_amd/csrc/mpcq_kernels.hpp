@@ -250,6 +250,7 @@ struct DevState {
   double run_dt;    // plant substep
   unsigned long long* prof;   // [B][PF_N] (diagnostic build only)
   int* chk;         // [16] first violation found by the checked build (-DMPCQ_CHECKED), nullptr otherwise
+  const int* order; // [B] workgroup p runs quadrotor order[p] (order_kernel: expensive quadrotors first); nullptr: p itself
 };
 
 // ------------------------------------------------------------------ LDS layout
@@ -1961,11 +1962,14 @@ __device__ inline int chunk_have(int len, int idx, int N, int skip) {
   return 0;
 }
 
+#ifndef MPCQ_MIN_WAVES_PER_EU
+#define MPCQ_MIN_WAVES_PER_EU 1
+#endif
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__global__ void __launch_bounds__(64) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
+__global__ void __launch_bounds__(64, MPCQ_MIN_WAVES_PER_EU) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
   const int tid = lane_id();
   const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
-  const int b = blockIdx.x;
+  const int b = st.order ? st.order[blockIdx.x] : (int)blockIdx.x;
   const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
 #ifdef MPCQ_CHECKED
   if (tid == 0) *reinterpret_cast<int**>(smem_raw) = st.chk;   // where violations are recorded (ck_rec)
@@ -2338,6 +2342,52 @@ static __global__ void stats_kernel(const double* stats, const int* status, int 
       sh[3][0] = sh[3][0] > sh[3][t] ? sh[3][0] : sh[3][t];
     }
     for (int k = 0; k < 5; ++k) out5[k] = sh[k][0];
+  }
+}
+
+
+// ------------------------------------------------------------------ launch order of a lockstep period (large batches)
+// A batch larger than the device holds at once runs as a stream of workgroups, and the launch ends with its last one: the
+// expensive quadrotors have to start first (longest-processing-time-first list scheduling).  What this period's solve will
+// cost is predicted from the previous one (qp_iter: passes + interior-point iterations; a quadrotor that fell back or carries
+// the flip mark will do so again more often than not).  Workgroup p runs quadrotor order[p]; the permutation stays inside the
+// classes p mod 8 -- workgroups are dealt round-robin over the 8 XCDs, so every XCD gets its own share of the expensive ones
+// first and a quadrotor keeps its XCD -- each class in descending predicted cost (stable counting sort, 16 bins).
+// One workgroup of 256 lanes per class; dynamic LDS: 16 x 256 counters + 16 bin bases.
+constexpr int ORD_BINS = 16, ORD_THREADS = 256, ORD_CLASSES = 8;
+constexpr size_t ORD_LDS = (size_t)(ORD_BINS * ORD_THREADS + ORD_BINS) * sizeof(int);
+__host__ __device__ inline int order_bin(int q) {   // bin 0 = most expensive
+  const int total = q % 1000, marked = (q / 1000) % 100 != 0;   // fallback solve (x 1000) or flip mark (x 10000)
+  int cost = q == 0 ? ORD_BINS - 1 : (total < ORD_BINS - 1 ? total : ORD_BINS - 1);   // cold start: interior point from scratch
+  if (marked && cost < 8) cost = 8;
+  return ORD_BINS - 1 - cost;
+}
+static __global__ void __launch_bounds__(ORD_THREADS) order_kernel(const int* qp_iter, int B, int* order) {
+  int* cnt = reinterpret_cast<int*>(smem_raw);          // [ORD_BINS][ORD_THREADS]
+  int* base = cnt + ORD_BINS * ORD_THREADS;             // [ORD_BINS]
+  const int x = blockIdx.x, t = threadIdx.x;
+  const int n = (B - x + ORD_CLASSES - 1) / ORD_CLASSES;      // members of the class: b = 8 j + x < B
+  const int chunk = (n + ORD_THREADS - 1) / ORD_THREADS;
+  const int j0 = t * chunk < n ? t * chunk : n, j1 = j0 + chunk < n ? j0 + chunk : n;
+  for (int k = 0; k < ORD_BINS; ++k) cnt[k * ORD_THREADS + t] = 0;
+  for (int j = j0; j < j1; ++j) cnt[order_bin(qp_iter[ORD_CLASSES * j + x]) * ORD_THREADS + t] += 1;   // own column: no race
+  __syncthreads();
+  if (t < ORD_BINS) {   // exclusive scan of bin t over the lanes
+    int run = 0;
+    for (int u = 0; u < ORD_THREADS; ++u) { const int c = cnt[t * ORD_THREADS + u]; cnt[t * ORD_THREADS + u] = run; run += c; }
+    base[t] = run;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int k = 0; k < ORD_BINS; ++k) { const int c = base[k]; base[k] = run; run += c; }
+  }
+  __syncthreads();
+  for (int j = j0; j < j1; ++j) {
+    const int k = order_bin(qp_iter[ORD_CLASSES * j + x]);
+    const int pos = base[k] + cnt[k * ORD_THREADS + t];
+    cnt[k * ORD_THREADS + t] += 1;
+    order[ORD_CLASSES * pos + x] = ORD_CLASSES * j + x;
   }
 }
 

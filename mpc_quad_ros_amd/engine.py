@@ -31,6 +31,15 @@ def qp_warm_exit(it):
     return np.asarray(it) // 100000
 
 
+def order_bin(it):
+    """Cost bin of mpcq::order_kernel (0 = predicted most expensive) for a qp_iter value of the previous period."""
+    it = np.asarray(it)
+    total = it % 1000
+    cost = np.where(it == 0, 15, np.minimum(total, 15))
+    cost = np.where(((it // 1000) % 100 != 0) & (cost < 8), 8, cost)
+    return 15 - cost
+
+
 WARM_BUDGET, WARM_PINS, WARM_WRONG, WARM_BOUNCE, WARM_NUMERIC, WARM_SKIPPED = 1, 2, 3, 4, 5, 6
 SOLVE_LOW_ACCURACY = 8
 
@@ -133,6 +142,12 @@ class Engine:
     def get_qp_iter(self):
         out = np.zeros(self.B, np.int32)
         self._check(self.lib.mpcq_get_qp_iter(self.h, _lib.i(out)))
+        return out
+
+    def get_block_order(self):
+        """Launch order of the last lockstep period: workgroup p ran quadrotor out[p] (identity when unused)."""
+        out = np.zeros(self.B, np.int32)
+        self._check(self.lib.mpcq_get_block_order(self.h, _lib.i(out)))
         return out
 
     def get_time(self):

@@ -31,7 +31,7 @@ def _check(line, n):
 
 def test_single_rank_line():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tests", "run_bench_emu.py"), "--steps", "2", "--warmup", "1", "--preroll", "3",
-                                   "--batch", "2", "--horizon", "5", "--nb", "10", "--no-cpu-baseline", "--no-alt"], cwd=ROOT)
+                                   "--batch", "2", "--horizon", "5", "--nb", "10", "--no-cpu-baseline", "--no-alt", "--steady", "3"], cwd=ROOT)
     lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = _check(lines[0], 1)
@@ -39,6 +39,10 @@ def test_single_rank_line():
     p = d["parity_on_workload"]
     assert p["quad_steps"] == 2 * 30 and p["max_rel_dev"] < 1e-7 and p["failed"] == 0
     assert d["roofline"]["traffic"] is None and "no PMC profile" in d["roofline"]["traffic_note"]
+    # the representative rate next to the driver's window, and the per-rank record (one rank: min = mean = max = the line's own)
+    assert d["steady_state"]["steps"] == 3 and d["steady_state"]["value"] > 0
+    pr = d["per_rank"]
+    assert pr["steps_per_s"]["min"] == pr["steps_per_s"]["max"] and len(pr["ranks"]) == 1 and 0.5 < d["efficiency_vs_best_rank"] <= 1.0 + 1e-9
 
 
 def test_two_ranks_under_torchrun():
@@ -46,10 +50,30 @@ def test_two_ranks_under_torchrun():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "run_bench_emu.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--preroll", "3",
-           "--batch", "2", "--horizon", "5", "--nb", "10"]
+           "--batch", "2", "--horizon", "5", "--nb", "10", "--no-strict-rccl"]      # (no RCCL without GPUs: the statistic goes over the host group, and the line says so)
     out = subprocess.check_output(cmd, cwd=ROOT, stderr=subprocess.STDOUT, timeout=600)
     lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.decode()[-2000:]
     d = _check(lines[0], 2)
     assert d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "shard2"
-    assert "cpu_baseline" not in d and "alt_precision" not in d        # rank-0, N=1 only
+    assert "cpu_baseline" not in d and "alt_precision" not in d and "steady_state" not in d        # rank-0, N=1 only
+    # every rank's own clock, gathered over the host group: the line carries min / mean / max and the efficiency against the best rank
+    pr = d["per_rank"]
+    assert len(pr["ranks"]) == 2 and {"ms_per_step", "kernel_avg_ms", "steps_per_s"} <= set(pr["ranks"][0])
+    for k in ("ms_per_step", "kernel_avg_ms", "steps_per_s"):
+        assert pr[k]["min"] <= pr[k]["mean"] <= pr[k]["max"]
+    assert abs(d["efficiency_vs_best_rank"] - d["value"] / (2 * pr["steps_per_s"]["max"])) < 1e-12 and d["efficiency_vs_best_rank"] <= 1.0 + 1e-9
+    assert d["config"]["batch_per_gpu"] == 2 and d["config"]["rccl_ok"] is False and "gloo" in d["config"]["stats_reduce"]
+
+
+def test_two_ranks_strict_rccl_is_the_default():
+    """Under WORLD_SIZE > 1 a reduction that did not go through RCCL fails the run unless --no-strict-rccl says otherwise."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "run_bench_emu.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--preroll", "1",
+           "--batch", "1", "--horizon", "5", "--nb", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["config"]["rccl_ok"] is False      # the line is still printed, and says which reduction ran

@@ -107,6 +107,42 @@ def test_emu_lane_order_independent_closed_loop():
     assert eval(out) == fwd
 
 
+def test_emu_block_order_is_cost_sorted_and_changes_nothing():
+    """mpcq::order_kernel (launch order of a lockstep period, large batches): a permutation inside the classes p mod 8, every
+    class in ascending cost bin of the previous period's qp_iter (bin 0 = predicted most expensive), and the results of the
+    launch do not depend on it (B = 21: classes of unequal size)."""
+    from mpc_quad_ros_amd.engine import order_bin
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N = 21, 5
+    traj, lens = swarm_trajectories(5, 0, B)
+    rng = np.random.default_rng(1)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    x0[:, :3] += rng.normal(0, 0.5, (B, 3)); x0[:, 7:10] += rng.normal(0, 1.0, (B, 3))
+    e1 = make(EngineConfig(batch=B, N=N, quad=hummingbird(), tune=dict(block_order=1)))
+    e2 = make(EngineConfig(batch=B, N=N, quad=hummingbird(), tune=dict(block_order=2)))
+    for e in (e1, e2):
+        e.set_trajectories(traj, lens); e.sim_reset(x0); e.sim_steps(3, 2, 5e-3)
+    (xa, wa), (xb, wb) = e1.sim_get_state(), e2.sim_get_state()
+    assert np.array_equal(xa, xb) and np.array_equal(wa, wb) and np.array_equal(e1.get_state()["X"], e2.get_state()["X"])
+    assert np.array_equal(e1.get_block_order(), np.arange(B))
+    # a previous-period record that spans several cost bins, marks included (any values are a valid input)
+    it_prev = np.array([0, 1, 2, 1003, 11005, 3, 1, 612006, 1, 2, 1, 9, 1, 1, 14, 1, 2, 1, 1001, 1, 4], np.int32)
+    e2.set_solver_state(qp_iter=it_prev)
+    e2.sim_steps(1, 2, 5e-3)
+    order = e2.get_block_order()
+    assert sorted(order) == list(range(B))
+    for x in range(8):
+        cls = order[x::8]
+        assert np.all(cls % 8 == x)
+        bins = order_bin(it_prev[cls])
+        assert np.all(np.diff(bins) >= 0), (x, cls, bins)
+        for k in np.unique(bins):            # stable inside a bin
+            assert np.all(np.diff(cls[bins == k]) > 0)
+    assert (e2.get_status() == 0).all()
+    e1.close(); e2.close()
+
+
 def test_emu_f32_qp_mode_within_budget():
     # TQ = float: state and QP data still formed in double; north_star budget 1e-4 relative control deviation
     assert pc.case_swarm_closed_loop(make, B=2, N=20, nb=10, K=10, precision=1) < 1e-4

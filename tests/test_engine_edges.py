@@ -119,7 +119,7 @@ def _versioned_create(lib_path):
     for size in (CConfig.device.offset, ctypes.sizeof(CConfig) + 8):
         assert lib.mpcq_create_sized(ctypes.cast(raw, ctypes.c_void_p), size, ctypes.byref(h)) != 0
         assert b"size" in lib.mpcq_last_error()
-    assert b"0.3" in lib.mpcq_version()
+    assert b"0.4" in lib.mpcq_version()
 
 
 def _reference_format_log(lib):

@@ -90,6 +90,43 @@ def test_config3_per_rank_shape_against_oracle():
     assert np.array_equal(e.get_state()["idx"], np.full(n, K))
 
 
+def test_block_order_changes_nothing():
+    """Large batches run their lockstep periods in the launch order of mpcq::order_kernel (quadrotors predicted expensive
+    first, mpcq_tuning.block_order).  B = 2 560 (more than the device holds at once, not a multiple of the class structure's
+    natural sizes) on the bench workload, in flight: the ordered launches equal the identity-ordered ones bit for bit, the
+    order is a permutation inside the classes p mod 8, each class in ascending cost bin of the previous period."""
+    import bench
+    from mpc_quad_ros_amd.engine import order_bin
+    B, pre, K = 2560, 150, 25
+    refs = bench.workload(2026, 0, B, pre + K + 1)
+    engines = []
+    for bo in (1, 0):      # 0 = automatic: on, since B exceeds the resident capacity
+        e = Engine(EngineConfig(batch=B, N=20, quad=hummingbird(), nb=10, basis=rgp_basis_linspace(12.0, 10), tune=dict(block_order=bo)))
+        e.set_trajectories(*refs); e.sim_reset(np.tile(X0, (B, 1)))
+        e.sim_run(pre, 2, 5e-3)
+        e.sim_steps(K, 2, 5e-3)
+        engines.append(e)
+    a, b = engines
+    it_prev = b.get_qp_iter()
+    assert len(np.unique(order_bin(it_prev))) >= 3          # the workload spans several cost bins here
+    for e in engines:
+        e.sim_steps(1, 2, 5e-3)
+    assert np.array_equal(a.get_block_order(), np.arange(B))
+    order = b.get_block_order()
+    assert np.array_equal(np.sort(order), np.arange(B))
+    for x in range(8):
+        cls = order[x::8]
+        assert np.all(cls % 8 == x)
+        bins = order_bin(it_prev[cls])
+        assert np.all(np.diff(bins) >= 0)
+    (xa, wa), (xb, wb) = a.sim_get_state(), b.sim_get_state()
+    assert np.array_equal(xa, xb) and np.array_equal(wa, wb)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(a.get_qp_iter(), b.get_qp_iter()) and np.array_equal(a.get_tracking_stats(), b.get_tracking_stats())
+
+
 class _Hip:
     """Raw device buffers for the device-pointer entry point (no torch on this path)."""
     def __init__(self):
