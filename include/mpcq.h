@@ -66,7 +66,7 @@ typedef enum mpcq_status {
  * precision; validated by mpcq_create (MPCQ_ERR_INVALID outside the stated range).  The defaults were measured on two
  * workloads; results do not depend on them beyond rounding.  With MPCQ_TUNING=1 in the
  * environment, MPCQ_WARM_MAX, MPCQ_WARM_RETRY, MPCQ_FLIP_MAX, MPCQ_ABORT_PINS, MPCQ_ABORT_WRONG, MPCQ_POLISH_MAX,
- * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global, MPCQ_GENERIC=1, MPCQ_BLOCK_ORDER override
+ * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global|compact, MPCQ_GENERIC=1, MPCQ_BLOCK_ORDER override
  * the corresponding field (measurement scripts only; without MPCQ_TUNING=1 the environment is not consulted). */
 typedef struct mpcq_tuning {
   int32_t warm_max;     /* passes of the warm active-set attempt, 1..64 (default 6 f64 / 12 f32) */
@@ -75,7 +75,8 @@ typedef struct mpcq_tuning {
   int32_t abort_pins;   /* warm attempt given up when its first pass pins this many inputs, 1..512; -1: never (default 10, N/2 for N > 20) */
   int32_t abort_wrong;  /* ... or a multiplier check finds this many wrong signs, 1..512; -1: never (default 9, 9N/20 for N > 20) */
   int32_t polish_max;   /* active-set passes behind the interior point, 1..64; -1: none, interior point to qp_tol (default 16 f64 / 12 f32) */
-  int32_t stage_mem;    /* placement of the per-stage records: 0 automatic, 1 LDS, 2 global memory (L2) */
+  int32_t stage_mem;    /* layout of the per-instance working set: 0 automatic, 1 all LDS, 2 per-stage records in global memory (L2),
+                           3 compact (since 0.4: Riccati gains in global memory as well, <= 256 registers: more instances per CU) */
   int32_t generic_kernel; /* 1: the any-shape kernel instance even where a shape-specialised one exists */
   double pin_ratio;     /* interior point -> working set: pinned where multiplier > pin_ratio x slack, (0, 1e3] (default 0.2 f64 / 1 f32) */
   double ipm_mu0;       /* complementarity of the interior start in units of the gradient scale, [1e-12, 1] (default 1e-4) */

@@ -18,7 +18,9 @@
 
 namespace mpcq {   // mpcq_spec.hip, one translation unit per specialised shape
 template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<T>, const int);
-#if defined(MPCQ_CHECKED) || defined(MPCQ_ONE_SHAPE)   // the checked build compiles for tens of minutes per specialised shape: only the headline shape has one there (MPCQ_ONE_SHAPE: quick A/B variants, `make variant SHAPES=20_10 EXTRA=-DMPCQ_ONE_SHAPE`)
+#if defined(MPCQ_SHAPE_LIST)   // reproducer builds (tools/repro_codegen): -D'MPCQ_SHAPE_LIST(X)=X(20,10) X(20,20)'
+#define MPCQ_SPEC_SHAPES(X) MPCQ_SHAPE_LIST(X)
+#elif defined(MPCQ_CHECKED) || defined(MPCQ_ONE_SHAPE)   // the checked build compiles for tens of minutes per specialised shape: only the headline shape has one there (MPCQ_ONE_SHAPE: quick A/B variants, `make variant SHAPES=20_10 EXTRA=-DMPCQ_ONE_SHAPE`)
 #ifndef MPCQ_ONE_N
 #define MPCQ_ONE_N 20
 #define MPCQ_ONE_NB 10
@@ -28,23 +30,38 @@ template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<
 #define MPCQ_SPEC_SHAPES(X) X(20, 10) X(20, 20) X(50, 50)   // BASELINE configs[1] (and [3] per rank), configs[2], configs[4]
 #endif
 // (one more macro level so that shapes given as macros -- MPCQ_ONE_N -- are expanded before the names are pasted)
-#define MPCQ_DECL_(n, nb) StepFn<double> spec_lock_f64_##n##_##nb(bool gab); StepFn<float> spec_lock_f32_##n##_##nb(bool gab);
+#define MPCQ_DECL_(n, nb) StepFn<double> spec_lock_f64_##n##_##nb(int layout); StepFn<float> spec_lock_f32_##n##_##nb(int layout);
 #define MPCQ_DECL(n, nb) MPCQ_DECL_(n, nb)
 MPCQ_SPEC_SHAPES(MPCQ_DECL)
 #undef MPCQ_DECL
+// specialised free-running fp64 instances: the shapes of MPCQ_SPEC_RUN_SHAPES (Makefile: SPEC_RUN_SHAPES; reproducer builds: every shape)
+#if defined(MPCQ_SPEC_RUN) && !defined(MPCQ_SPEC_RUN_SHAPES)
+#define MPCQ_SPEC_RUN_SHAPES(X) MPCQ_SPEC_SHAPES(X)
+#endif
+#ifdef MPCQ_SPEC_RUN_SHAPES
+#define MPCQ_DECLR_(n, nb) StepFn<double> spec_run_f64_##n##_##nb(int layout);
+#define MPCQ_DECLR(n, nb) MPCQ_DECLR_(n, nb)
+MPCQ_SPEC_RUN_SHAPES(MPCQ_DECLR)
+#endif
 }
-#define MPCQ_TRY64_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_lock_f64_##n##_##nb_(gab);
-#define MPCQ_TRY32_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_lock_f32_##n##_##nb_(gab);
+#define MPCQ_TRY64_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_lock_f64_##n##_##nb_(layout);
+#define MPCQ_TRY32_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_lock_f32_##n##_##nb_(layout);
 #define MPCQ_TRY64(n, nb_) MPCQ_TRY64_(n, nb_)
 #define MPCQ_TRY32(n, nb_) MPCQ_TRY32_(n, nb_)
-static mpcq::StepFn<double> spec_step(int N, int nb, bool gab, double*) {   // lockstep instance of a specialised shape, or nullptr
+static mpcq::StepFn<double> spec_step(int N, int nb, int layout, double*) {   // lockstep instance of a specialised shape (layout: lds_layout), or nullptr
   MPCQ_SPEC_SHAPES(MPCQ_TRY64)
   return nullptr;
 }
-static mpcq::StepFn<float> spec_step(int N, int nb, bool gab, float*) {
+static mpcq::StepFn<float> spec_step(int N, int nb, int layout, float*) {
   MPCQ_SPEC_SHAPES(MPCQ_TRY32)
   return nullptr;
 }
+#ifdef MPCQ_SPEC_RUN_SHAPES
+#define MPCQ_TRYR_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_run_f64_##n##_##nb_(layout);
+#define MPCQ_TRYR(n, nb_) MPCQ_TRYR_(n, nb_)
+static mpcq::StepFn<double> spec_run(int N, int nb, int layout, double*) { MPCQ_SPEC_RUN_SHAPES(MPCQ_TRYR) return nullptr; }
+static mpcq::StepFn<float> spec_run(int, int, int, float*) { return nullptr; }
+#endif
 
 namespace {
 
@@ -189,6 +206,7 @@ struct EngineT : mpcq_engine {
   mpcq::DevState<T> st;
   mpcq::Lds L;
   size_t lds_bytes = 0;
+  int resident_per_cu = 0;   // workgroups of the lockstep instance one CU holds at once (LDS and registers)
   void (*kstep)(const mpcq::DevModel<T>, const mpcq::DevState<T>, const int) = nullptr;
   void (*krun)(const mpcq::DevModel<T>, const mpcq::DevState<T>, const int) = nullptr;   // free-running variant (mpcq_sim_run)
   std::vector<double> hbufd;
@@ -201,7 +219,6 @@ struct EngineT : mpcq_engine {
   double* d_cmd = nullptr;   // [B*8] rotor thrusts, collective thrust, body rates (mpcq_get_command); also the chunk read-back
   size_t cmd_elems = 0;
   std::vector<T> hbuf;
-  std::vector<int> hlen;
   std::vector<double> Kx;
 
   ~EngineT() override {
@@ -360,47 +377,82 @@ struct EngineT : mpcq_engine {
     if ((rc = dalloc(d_vb, Bz * 3))) return rc;
     if ((rc = dalloc(d_ad, Bz * 3))) return rc;
     if ((rc = dalloc(d_stats5, 8))) return rc;
-#ifdef MPCQ_PROFILE
+#if defined(MPCQ_PROFILE) || defined(MPCQ_TRACE_NAN)
     if ((rc = dalloc(st.prof, Bz * mpcq::PF_N))) return rc;
 #endif
 #ifdef MPCQ_CHECKED
     if ((rc = dalloc(st.chk, 16))) return rc;
 #endif
+#ifdef MPCQ_DUMP_AT
+    if ((rc = dalloc(m.dbg, Bz * 4096))) return rc;
+#endif
     st.tlen = d_tlen; st.traj = nullptr; st.x_meas = d_xin;
-    // Placement of the per-stage records (AB'', c, qv): LDS when the whole batch is resident at once that way,
-    // otherwise global memory (L2 / MALL) if that lets more instances share a CU.  mpcq_config.tune.stage_mem overrides.
+    // Layout of the working set (mpcq::lds_layout): 0 everything in LDS | 1 the per-stage records (AB'', c, qv) in the per-instance
+    // global record (L2 / MALL) | 2 "compact": the Riccati gains there as well, instances limited to 256 registers -- a second wave
+    // per SIMD.  Rule: LDS when the whole batch is resident at once that way, otherwise the layout that holds more instances per CU,
+    // the compact one only for batches beyond what layout 0 / 1 hold at once.  mpcq_config.tune.stage_mem overrides.
     int n_cu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
-    const size_t lds_cu = 160 * 1024;
-    const mpcq::Lds Ll = mpcq::lds_layout(N, nb, 0), Lg = mpcq::lds_layout(N, nb, 1);
-    const size_t bl = mpcq::lds_bytes<T>(Ll), bg = mpcq::lds_bytes<T>(Lg);
-    const size_t occ_l = bl <= lds_cu ? lds_cu / bl : 0, occ_g = bg <= lds_cu ? lds_cu / bg : 0;
-    bool gab = occ_l == 0 || (occ_g > occ_l && (size_t)B > occ_l * n_cu);
-    if (tu.stage_mem) gab = tu.stage_mem == 2;
-    if (const char* t = env ? getenv("MPCQ_STAGE_MEM") : nullptr) gab = t[0] == 'g' || t[0] == 'G';
-    if (gab && occ_g == 0) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS (N/nb too large for this precision)");
-    if (!gab && occ_l == 0) return fail(MPCQ_ERR_INVALID, "per-instance working set exceeds 160 KiB LDS with the stage records in LDS (tune.stage_mem = 1)");
-    m.gab = gab ? 1 : 0;
-    if (env && getenv("MPCQ_VERBOSE")) fprintf(stderr, "mpcq: stage records in %s, LDS %zu B per instance (%zu per CU), lds-only layout %zu B (%zu per CU)\n", gab ? "global memory" : "LDS", gab ? bg : bl, gab ? occ_g : occ_l, bl, occ_l);
-    L = gab ? Lg : Ll;
-    lds_bytes = gab ? bg : bl;
-    if ((rc = dalloc(st.stage, Bz * L.gtotal))) return rc;   // stage records (global placement) + multiplier rows
+    const bool generic = ienv("MPCQ_GENERIC", tu.generic_kernel) != 0;
+    mpcq::Lds Ls[3];
+    size_t bytes[3], occ[3];
+    mpcq::StepFn<T> ks[3], kr[3];
+    ks[0] = &mpcq::step_kernel<mpcq::Cfg<T, false>>; ks[1] = &mpcq::step_kernel<mpcq::Cfg<T, true>>; ks[2] = &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, false, true>>;
+    // free-running launches (mpcq_sim_run): the any-shape instance, replaced below by a shape-specialised one where mpcq_spec.hip has it
+    kr[0] = &mpcq::step_kernel<mpcq::Cfg<T, false, 0, -1, true>>; kr[1] = &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true>>;
+    kr[2] = &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true, true>>;
+    for (int l = 0; l < 3; ++l) {
+      Ls[l] = mpcq::lds_layout(N, nb, l);
+      bytes[l] = mpcq::lds_bytes<T>(Ls[l]);
+      // lockstep launches: shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
+      if (!generic)
+        if (auto k = spec_step(N, nb, l, (T*)nullptr)) ks[l] = k;
+      occ[l] = 0;
+      if (bytes[l] <= 160 * 1024) {   // resident workgroups per CU: LDS and registers of the instance that would run
+        int nblk = 0;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ks[l]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes[l]));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(ks[l]), 64, bytes[l]) == hipSuccess && nblk > 0) occ[l] = (size_t)nblk;
+        else occ[l] = (160 * 1024) / bytes[l];
+      }
+    }
+    int layout = (occ[0] == 0 || (occ[1] > occ[0] && (size_t)B > occ[0] * n_cu)) ? 1 : 0;
+    // (the compact instance is a few per cent slower per wave -- 256 registers, gains through L2 --, so it has to save a whole
+    //  round of workgroups to pay: measured at B = 2 048, N = 20: two rounds either way, 5.03 M steps/s against 4.83 M compact)
+    {
+      const size_t r1 = occ[layout] * n_cu, r2 = occ[2] * n_cu;
+      if (occ[2] > occ[layout] && ((size_t)B + r2 - 1) / r2 < ((size_t)B + r1 - 1) / r1) layout = 2;
+    }
+    if (tu.stage_mem) layout = tu.stage_mem - 1;
+    if (const char* t = env ? getenv("MPCQ_STAGE_MEM") : nullptr) layout = (t[0] == 'c' || t[0] == 'C') ? 2 : ((t[0] == 'g' || t[0] == 'G') ? 1 : 0);
+    if (occ[layout] == 0)
+      return fail(MPCQ_ERR_INVALID, layout == 0 ? "per-instance working set exceeds 160 KiB LDS with the stage records in LDS (tune.stage_mem = 1)"
+                                                : "per-instance working set exceeds 160 KiB LDS (N/nb too large for this precision)");
+    m.gab = layout;
+    const bool gab = layout != 0;
+    if (env && getenv("MPCQ_VERBOSE"))
+      fprintf(stderr, "mpcq: layout %d (%s), LDS %zu B per instance, %zu instances per CU; layouts 0/1/2: %zu/%zu/%zu B, %zu/%zu/%zu per CU\n", layout,
+              layout == 0 ? "all LDS" : (layout == 1 ? "stage records in global memory" : "compact: stage records and gains in global memory"), bytes[layout], occ[layout],
+              bytes[0], bytes[1], bytes[2], occ[0], occ[1], occ[2]);
+    L = Ls[layout];
+    lds_bytes = bytes[layout];
+    resident_per_cu = (int)occ[layout];
+    if ((rc = dalloc(st.stage, Bz * L.gtotal))) return rc;   // stage records (global placement) + multiplier rows + cost-to-go tiles (+ gains)
     // Launch order of a lockstep period: a batch beyond what the device holds at once is a stream of workgroups that ends with
     // its last one, so the quadrotors predicted to be expensive go first (mpcq::order_kernel in front of every step launch).
     // A batch that is resident as a whole starts all at once: no order needed.  tune.block_order: 1 = never, 2 = always.
     {
-      const size_t resident = (gab ? occ_g : occ_l) * (size_t)n_cu;
+      const size_t resident = occ[layout] * (size_t)n_cu;
       const int bo = ienv("MPCQ_BLOCK_ORDER", tu.block_order);
       use_order = bo == 2 || (bo == 0 && (size_t)B > resident);
       if (use_order && (rc = dalloc(d_order, Bz))) return rc;
     }
-    kstep = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false>>;
-    // free-running launches (mpcq_sim_run): the any-shape instance for every shape (mpcq_spec.hip says why)
-    krun = gab ? &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true>> : &mpcq::step_kernel<mpcq::Cfg<T, false, 0, -1, true>>;
-    // lockstep launches: shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
-    if (!ienv("MPCQ_GENERIC", tu.generic_kernel)) {
-      if (auto k = spec_step(N, nb, gab, (T*)nullptr)) kstep = k;
-    }
+    kstep = ks[layout];
+    krun = kr[layout];
+#ifdef MPCQ_SPEC_RUN_SHAPES
+    if (!generic)
+      if (auto k = spec_run(N, nb, layout, (T*)nullptr)) krun = k;
+#endif
+    (void)gab;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(krun), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kstep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mpcq::regress_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -719,7 +771,7 @@ struct EngineT : mpcq_engine {
     return 0;
   }
   int get_prof(unsigned long long* out) override {
-#ifdef MPCQ_PROFILE
+#if defined(MPCQ_PROFILE) || defined(MPCQ_TRACE_NAN)
     HIP_TRY(hipMemcpyAsync(out, st.prof, (size_t)B * mpcq::PF_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
@@ -742,17 +794,12 @@ struct EngineT : mpcq_engine {
   int set_state(const double* X, const double* U, const double* mu, const double* C, const double* xpp, const int32_t* hp,
                 const int32_t* idx) override {
     int rc;
-    // a cursor outside its trajectory would make the step kernel read reference rows out of range (only the checked build
-    // would notice): refused here.  Without trajectories (explicit path) the cursor only counts periods: >= 0.
-    if (idx) {
-      if (have_traj) {
-        hlen.resize(B);
-        HIP_TRY(hipMemcpyAsync(hlen.data(), d_tlen, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-      }
+    // a negative cursor would make the step kernel read reference rows in front of its trajectory (only the checked build would
+    // notice): refused here.  A cursor at or beyond the end is legal (get_reference_chunk repeats the last row, src/utils/utils.py:897-931).
+    const bool unchecked = tuning_env && getenv("MPCQ_SKIP_STATE_CHECKS");   // tests of the checked build provoke a violation this way
+    if (idx && !unchecked)
       for (int b = 0; b < B; ++b)
-        if (idx[b] < 0 || (have_traj && idx[b] > hlen[b])) return fail(MPCQ_ERR_INVALID, "mpcq_set_state: trajectory cursor outside [0, length]");
-    }
+        if (idx[b] < 0) return fail(MPCQ_ERR_INVALID, "mpcq_set_state: negative trajectory cursor");
     if (hp)
       for (int b = 0; b < B; ++b)
         if (hp[b] != 0 && hp[b] != 1) return fail(MPCQ_ERR_INVALID, "mpcq_set_state: has_prev must be 0 or 1");
@@ -808,7 +855,7 @@ int mpcq_create_sized(const mpcq_config* c_in, uint64_t cfg_size, mpcq_engine** 
     auto frange = [](double v, double lo, double hi) { return v == 0 || (v >= lo && v <= hi); };   // NaN fails both
     if (!irange(t.warm_max, 1, 64, false) || !irange(t.warm_retry, 1, 64, false) || !irange(t.flip_max, 1, 512, true) ||
         !irange(t.abort_pins, 1, 512, true) || !irange(t.abort_wrong, 1, 512, true) || !irange(t.polish_max, 1, 64, true) ||
-        !irange(t.stage_mem, 1, 2, false) || !irange(t.generic_kernel, 1, 1, false) || !irange(t.block_order, 1, 2, false) || t.reserved0 != 0)
+        !irange(t.stage_mem, 1, 3, false) || !irange(t.generic_kernel, 1, 1, false) || !irange(t.block_order, 1, 2, false) || t.reserved0 != 0)
       return fail(MPCQ_ERR_INVALID, "mpcq_config.tune: integer field out of range (see mpcq.h)");
     if (!frange(t.pin_ratio, 1e-300, 1e3) || !frange(t.ipm_mu0, 1e-12, 1.0) || !(t.ipm_margin == 0 || (t.ipm_margin > 0 && t.ipm_margin < 0.5)) ||
         !frange(t.ipm_tol, 1e-300, 1e-1))
@@ -894,6 +941,14 @@ int mpcq_sim_get_state(mpcq_engine* e, double* x, double* w) { ENTER(e); return 
 int mpcq_get_kernel_time(mpcq_engine* e, double* s, int32_t* n) { ENTER(e); if (s) *s = e->ktime; if (n) *n = e->klaunches; return 0; }
 int mpcq_get_kernel_time_minmax(mpcq_engine* e, double* mn, double* mx) { ENTER(e); if (mn) *mn = e->kmin; if (mx) *mx = e->kmax; return 0; }
 int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]) { ENTER(e); return e->stats(out); }
+#ifdef MPCQ_DUMP_AT   /* reproducer builds only (tools/repro_codegen; not part of include/mpcq.h): [B][4096] doubles */
+int mpcq_debug_dump(mpcq_engine* e, double* out) {
+  ENTER(e);
+  double* src = e->cfg.precision == MPCQ_PRECISION_F64 ? static_cast<EngineT<double>*>(e)->m.dbg : static_cast<EngineT<float>*>(e)->m.dbg;
+  HIP_TRY(hipMemcpy(out, src, (size_t)e->B * 4096 * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
 /* diagnostic build only: per-instance phase cycle totals of the last step, [B][16] */
 int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out) { ENTER(e); return e->get_prof(out); }
 int mpcq_get_block_order(mpcq_engine* e, int32_t* out) { ENTER(e); if (!out) return fail(MPCQ_ERR_INVALID, "null argument"); return e->get_order(out); }

@@ -154,7 +154,8 @@ constexpr int ABS = NX * ABW;    // per-stage stride of AB'
 constexpr int PST = 256 + VS;     // stride of a stored cost-to-go (see Lds::pst)
 constexpr int MROW = 20;          // stride of a multiplier row (see Lds::mrow)
 constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded to 16)
-constexpr int SUBW = 41;         // per (stage, RK substage) record: x_s(13) Jvq(12) Jvv(9) Rz(3) pad
+// per (stage, RK substage) record of the shooting pass, what the sensitivity pass reads: q_s(4) r_s(3) | d vdot/dq (3x4) | d vdot/dv (3x3) | R[:,2]
+constexpr int SUB_Q = 0, SUB_R = 4, SUB_JQ = 7, SUB_JV = 19, SUB_RZ = 28, SUBW = 31;
 constexpr int SUBS = 4 * SUBW + 1;  // per-stage stride of the records (odd: lanes of different stages hit different banks)
 
 enum : int { MODE_TRAJ = 1, MODE_POST = 2, MODE_RUN = 4, MODE_PLANT_FIRST = 8, MODE_STATIC_GP = 16 };
@@ -220,6 +221,9 @@ struct DevModel {
   TQ L2inv[3], sf2[3], sn2[3];
   const TQ* basis;  // [3*nb]
   const TQ* Kxinv;  // [3*nb*nb]
+#ifdef MPCQ_DUMP_AT   // reproducer builds only (tools/repro_codegen): [B][4096] doubles, what the chosen point of the first interior-point iteration holds
+  double* dbg;
+#endif
 };
 
 template <typename TQ>
@@ -263,13 +267,19 @@ struct Lds {
   int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv;
   int sub, rgp, qtotal;
   int gab, zb, gx, gtotal;   // stage data (AB'', c, qv) in global memory? ; LDS zero block ; GP exchange scratch ; global elements per instance
+  int gk;                    // Riccati gains K, Lambda^-1 in the global record as well, and r0 / lb / ub inside the union (written behind the shooting)
   int mrow;                  // multiplier rows (always global): per stage 4 rows [M_a(13) | F_uu row(4) | gt_a | pad 2]
   int pst;                   // cost-to-go of every stage (always global): [P_i as accumulator tile (256) | p_i (16)]
 };
 __host__ __device__ inline int al4(int v) { return (v + 3) & ~3; }
+// gab: 0 everything in LDS | 1 the stage records (AB'', c, qv) in the per-instance global record | 2 = 1 + the Riccati gains there too
+// and the QP vectors r0 / lb / ub inside the union region (the "compact" layout of large batches: six instead of four quadrotors
+// per CU in fp64 at N = 20, i.e. a second wave on two of the four SIMDs).
 __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   Lds L;
   int o = 0, g = 0;
+  L.gk = gab == 2 ? 1 : 0;
+  gab = gab ? 1 : 0;
   auto take = [&](int n) { int r = o; o += al4(n); return r; };
   auto gtake = [&](int n) { int r = g; g += al4(n); return r; };
   L.X = take((N + 1) * NX);
@@ -298,22 +308,22 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
 #ifdef MPCQ_AB_PSTORE_DOUBLE   // A/B measurement only: every cost-to-go tile is written twice (what do the stores cost?)
   gtake(N * PST);
 #endif
-  L.gtotal = (g + 15) & ~15;
-  L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv);
+  if (!L.gk) { L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv); }
   L.alpha = take(3 * nb);
   L.basis = take(3 * nb);
   L.wq = take(3 * VS);   // stage / terminal state weights in internal order, input weights
   const int u0 = o;  // ---- union: shooting records | QP workspace | RGP workspace
   L.sub = u0;
   const int sub_end = u0 + al4(N * SUBS);
+  if (L.gk) { L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv); }
   L.z = take(nv); L.sl = take(nv); L.su = take(nv); L.ll = take(nv); L.lu = take(nv);
   L.dza = take(nv); L.dz = take(nv); L.rho = take(nv); L.act = take(nv); L.rt = take(nv);
   L.grad = take(N * VS);   // slots 10..13 of each stage: d objective / d z
   L.vin = take(N * VS);    // per-sweep input vector: slots 0..3 feed-forward k_i, slots 10..13 sweep-specific
   L.dx = take((N + 1) * VS);
   L.Dx = take((N + 1) * VS);
-  L.K = take(N * KS);
-  L.Linv = take(N * 16);
+  if (L.gk) { L.K = gtake(N * KS); L.Linv = gtake(N * 16); }
+  else { L.K = take(N * KS); L.Linv = take(N * 16); }
   L.sF = take(4 * VS);
   L.sT = take(4 * VS);   // rows 10..12 of T1'' (+ one row the fp64 hand-over writes unconditionally and nobody reads)
   L.stv = take(2 * VS);
@@ -323,6 +333,7 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   o = sub_end > qp_end ? sub_end : qp_end;
   if (rgp_end > o) o = rgp_end;
   L.qtotal = o;
+  L.gtotal = (g + 15) & ~15;
   return L;
 }
 template <typename TQ> __host__ __device__ inline size_t lds_bytes(const Lds& L) { return (size_t)CK_HDR + (size_t)L.dbytes + (size_t)L.qtotal * sizeof(TQ); }
@@ -380,10 +391,18 @@ template <int CTRL> __device__ inline double dpp(double v) {   // one v_mov_b64_
 // form -- DPP row_mask with the old value tied to the source -- was 0.6 % faster and was dropped: with it the free-running
 // instance of shape (20, 20) stopped reproducing the lockstep launches bit for bit, tests/test_gpu_parity.py::test_config2_full_size,
 // although every such instruction was emitted in place)
+#ifndef MPCQ_DPP_ROWMASK
 template <int CTRL, int ROWS, typename T> __device__ inline T dpp_rows(T v, int h) {   // h = lane >> 4
   const T r = dpp<CTRL>(v);
   return ((ROWS >> h) & 1) ? r : v;
 }
+#else   // reproducer builds only (tools/repro_codegen): the one-instruction form that was dropped in round 3
+template <int CTRL, int ROWS> __device__ inline int dpp_rows(int v, int) { CK_EXEC_FULL(2); return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xF, false); }
+template <int CTRL, int ROWS> __device__ inline float dpp_rows(float v, int h) { return __int_as_float(dpp_rows<CTRL, ROWS>(__float_as_int(v), h)); }
+template <int CTRL, int ROWS> __device__ inline double dpp_rows(double v, int h) {
+  return __hiloint2double(dpp_rows<CTRL, ROWS>(__double2hiint(v), h), dpp_rows<CTRL, ROWS>(__double2loint(v), h));
+}
+#endif
 // sum over the four 16-lane rows (lanes c, c+16, c+32, c+48), result on every lane: after v_permlane16_swap(v, v) the two
 // outputs hold rows (0,0,2,2) and (1,1,3,3), after v_permlane32_swap rows (0,1,0,1) and (2,3,2,3) -- their sum is the
 // butterfly step on every lane, no select (gfx950; no LDS, no SGPR round trip)
@@ -588,7 +607,7 @@ template <typename T> struct QC {
 };
 
 // f(x,u) of the OCP model (src/quad_opt.py:186-251 in the reference); when `sub` != nullptr also
-// writes the record the sensitivity pass needs: x(13) | d vdot/dq (3x4) | d vdot/dv (3x3) | R[:,2].
+// writes the record the sensitivity pass needs: q(4) r(3) | d vdot/dq (3x4) | d vdot/dv (3x3) | R[:,2]  (SUB_*).
 // GP term: m_d(s) = sum_j alpha_dj sf2 exp(-(s - X_j)^2 L2inv / 2), alpha = Kx^-1 mu.
 // gd >= 0: this lane sums only GP axis gd and the three lanes of a stage exchange the sums through gx (LDS).
 template <typename T, typename TG, typename PA, typename PB, typename PS, typename PG = TG*>
@@ -651,7 +670,9 @@ __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const
   }
   if (!sub) return;
 #pragma unroll
-  for (int i = 0; i < NX; ++i) sub[i] = x[i];
+  for (int i = 0; i < 4; ++i) sub[SUB_Q + i] = q[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sub[SUB_R + i] = r[i];
   const T qw = q[0], qx = q[1], qy = q[2], qz = q[3];
   const T dR[4][9] = {{0, -qz, qy, qz, 0, -qx, -qy, qx, 0},
                       {0, qy, qz, qy, -2 * qx, -qw, qz, qw, -2 * qx},
@@ -671,17 +692,17 @@ __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const
         val += dR[i][3 * row] * mg[0] + dR[i][3 * row + 1] * mg[1] + dR[i][3 * row + 2] * mg[2];
         val += R[3 * row] * dvb[0] + R[3 * row + 1] * dvb[1] + R[3 * row + 2] * dvb[2];
       }
-      sub[13 + row * 4 + i] = 2 * val;
+      sub[SUB_JQ + row * 4 + i] = 2 * val;
     }
   }
 #pragma unroll
   for (int row = 0; row < 3; ++row)
 #pragma unroll
     for (int col = 0; col < 3; ++col)
-      sub[25 + row * 3 + col] = gp ? (R[3 * row] * mp[0] * R[3 * col] + R[3 * row + 1] * mp[1] * R[3 * col + 1] +
+      sub[SUB_JV + row * 3 + col] = gp ? (R[3 * row] * mp[0] * R[3 * col] + R[3 * row + 1] * mp[1] * R[3 * col + 1] +
                                       R[3 * row + 2] * mp[2] * R[3 * col + 2])
                                    : T(0);
-  sub[34] = R[2]; sub[35] = R[5]; sub[36] = R[8];
+  sub[SUB_RZ] = R[2]; sub[SUB_RZ + 1] = R[5]; sub[SUB_RZ + 2] = R[8];
 }
 
 // one RK4 step of the NOMINAL model in double (quad_optimizer.discrete_dynamics on quad_nominal)
@@ -755,9 +776,12 @@ MPCQ_PHASE void plant_rk4(const M& m, double* x, const double* uin, double dt) {
 // One step-kernel instantiation per Cfg.  N = 0 / NB = -1 read the horizon and the RGP basis size from the
 // model at run time (any shape); fixed values turn every LDS offset, trip count and index division into a
 // compile-time constant for the shapes that matter (see mpcq_api.hip for the table of instances).
-template <typename T_, bool GAB_, int N_ = 0, int NB_ = -1, bool RUN_ = false> struct Cfg {
+template <typename T_, bool GAB_, int N_ = 0, int NB_ = -1, bool RUN_ = false, bool GK_ = false> struct Cfg {
   using T = T_;
   static constexpr bool GAB = GAB_;
+  static constexpr bool GK = GK_;     // compact layout (lds_layout gab = 2): gains in the global record, r0 / lb / ub written behind the shooting
+  static_assert(!GK_ || GAB_, "the compact layout keeps the stage records in global memory as well");
+  static constexpr int LAYOUT = GK_ ? 2 : (GAB_ ? 1 : 0);
   static constexpr bool RUN = RUN_;   // free-running closed loop: the kernel iterates over control periods
   static constexpr int N = N_, NB = NB_;
 };
@@ -829,8 +853,8 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L
       const TQ hs = s == 0 ? TQ(0) : (s == 3 ? h : h * TQ(0.5)), ws = (s == 0 || s == 3) ? TQ(1) : TQ(2);
 #pragma unroll
       for (int r = 0; r < NX; ++r) Z[r] = ((r == j) ? TQ(1) : TQ(0)) + hs * Sp[r];
-      const TQ qw = sub[3], qx = sub[4], qy = sub[5], qz = sub[6];
-      const TQ r0 = sub[10], r1 = sub[11], r2 = sub[12];
+      const TQ qw = sub[SUB_Q], qx = sub[SUB_Q + 1], qy = sub[SUB_Q + 2], qz = sub[SUB_Q + 3];
+      const TQ r0 = sub[SUB_R], r1 = sub[SUB_R + 1], r2 = sub[SUB_R + 2];
       TQ Sn[NX];
       Sn[0] = Z[7]; Sn[1] = Z[8]; Sn[2] = Z[9];
       Sn[3] = TQ(0.5) * (-r0 * Z[4] - r1 * Z[5] - r2 * Z[6] - qx * Z[10] - qy * Z[11] - qz * Z[12]);
@@ -839,11 +863,11 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L
       Sn[6] = TQ(0.5) * (r2 * Z[3] + r1 * Z[4] - r0 * Z[5] - qy * Z[10] + qx * Z[11] + qw * Z[12]);
 #pragma unroll
       for (int row = 0; row < 3; ++row) {
-        TQ t = ucol ? sub[34 + row] * tm : TQ(0);
+        TQ t = ucol ? sub[SUB_RZ + row] * tm : TQ(0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) t += sub[13 + row * 4 + c] * Z[3 + c];
+        for (int c = 0; c < 4; ++c) t += sub[SUB_JQ + row * 4 + c] * Z[3 + c];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) t += sub[25 + row * 3 + c] * Z[7 + c];
+        for (int c = 0; c < 3; ++c) t += sub[SUB_JV + row * 3 + c] * Z[7 + c];
         Sn[7 + row] = t;
       }
       Sn[10] = jur[0] + c10 * (r2 * Z[11] + r1 * Z[12]);
@@ -970,7 +994,7 @@ MPCQ_COLD void adjoint(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L) {
 
 // backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, bool polish) {
+MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, bool polish) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
@@ -979,15 +1003,29 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, con
     const int lj = lane < NU ? lane : 0;
     constexpr int PD = Depth<GAB>::PD;
     const bool arow = c < 10, prow = c >= 10 && c < NX;
-    TQ pc = 0, qa[PD + 1][4];
+    // gains: from LDS at their stage, from the global record (compact layout) as far ahead as the stage records
+    constexpr int KD = C::GK ? PD : 0;
+    TQ pc = 0, qa[PD + 1][4], kq[KD + 1];
+    V4<TQ> lq[KD + 1];
 #pragma unroll
     for (int d = 0; d < PD; ++d) km.load(A, N - 1 - d > 0 ? N - 1 - d : 0, qa[d]);
+#pragma unroll
+    for (int d = 0; d < KD; ++d) {
+      const int id = N - 1 - d > 0 ? N - 1 - d : 0;
+      kq[d] = Kb[L.K + id * KS + h * ABW + c];
+      lq[d] = ld4(Kb, L.Linv + id * 16 + lj * 4);
+    }
 #pragma unroll MPCQ_UNROLL_SWEEP
     for (int i = N - 1; i >= 0; --i) {
       km.load(A, i - PD > 0 ? i - PD : 0, qa[PD]);
+      {
+        const int ik = i - KD > 0 ? i - KD : 0;
+        kq[KD] = Kb[L.K + ik * KS + h * ABW + c];              // K[h][c]
+        lq[KD] = ld4(Kb, L.Linv + ik * 16 + lj * 4);
+      }
       const TQ rvc = S[L.vin + i * VS + c];                    // rho_j on lane column 10 + j
-      const TQ kk = S[L.K + i * KS + h * ABW + c];             // K[h][c]
-      const V4<TQ> li = ld4(S, L.Linv + i * 16 + lj * 4);
+      const TQ kk = kq[0];
+      const V4<TQ> li = lq[0];
       const TQ rtj = S[L.rt + i * NU + lj];
       TQ pv[4];
       l2g<TQ>(pc, h, pv);
@@ -1006,6 +1044,8 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, con
         S[L.vin + i * VS + lane] = (polish && rtj < TQ(0)) ? TQ(0) : kvj;
       }
       shift<TQ, PD>(qa);
+#pragma unroll
+      for (int d = 0; d < KD; ++d) { kq[d] = kq[d + 1]; lq[d] = lq[d + 1]; }
     }
     __syncthreads();
   }
@@ -1020,7 +1060,7 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, con
 // the sum over the four lane rows (hsum).  The result arrives lane-indexed (lane (.,c) holds row c); the next product needs
 // it group-uniform again: the inputs go through four v_readlane, the state through the LDS vector that the sweep writes anyway.
 template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, int dzo PF_ARG) {
+MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, int dzo PF_ARG) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
   constexpr bool F64 = sizeof(TQ) == 8;
   const Sel<TQ> sel(h);
@@ -1034,20 +1074,31 @@ MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const L
   const int j0 = F64 ? ((h + 2) & 3) : (h == 3 ? 2 : 0), j1 = F64 ? j0 : j0 + 1;
   const bool hasu = F64 || h >= 2;
   const int ko0 = L.K + j0 * ABW + c, ko1 = L.K + j1 * ABW + c;
-  TQ xc = 0, qa[PD + 1][4], k0, k1 = 0, g0, g1 = 0, gc = 0, gcn = 0;
+  // gain rows: one stage ahead from LDS; from the global record (compact layout) as far ahead as the stage records
+  constexpr int KD = C::GK ? PD : 1;
+  TQ xc = 0, qa[PD + 1][4], kq0[KD + 1], kq1[KD + 1], g0, g1 = 0, gc = 0, gcn = 0;
   if (affine) { xc = S[L.dx + c]; gc = S[L.Dx + c]; }
   else if (lane < VS) S[L.Dx + lane] = 0;
 #pragma unroll
   for (int d = 0; d < PD; ++d) rm.load(A, d < N ? d : N - 1, qa[d]);
-  k0 = S[ko0]; g0 = S[L.vin + j0];
-  if (!F64) { k1 = S[ko1]; g1 = S[L.vin + j1]; }
+#pragma unroll
+  for (int d = 0; d < KD; ++d) {
+    const int id = d < N ? d : N - 1;
+    kq0[d] = Kb[ko0 + id * KS];
+    kq1[d] = F64 ? TQ(0) : Kb[ko1 + id * KS];
+  }
+  g0 = S[L.vin + j0];
+  if (!F64) g1 = S[L.vin + j1];
 #pragma unroll MPCQ_UNROLL_SWEEP
   for (int i = 0; i < N; ++i) {
-    const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1;
+    const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1, ik = i + KD < N ? i + KD : N - 1;
     rm.load(A, ig, qa[PD]);
-    const TQ k0n = S[ko0 + ip * KS], g0n = S[L.vin + ip * VS + j0];
-    TQ k1n = 0, g1n = 0;
-    if (!F64) { k1n = S[ko1 + ip * KS]; g1n = S[L.vin + ip * VS + j1]; }
+    kq0[KD] = Kb[ko0 + ik * KS];
+    kq1[KD] = F64 ? TQ(0) : Kb[ko1 + ik * KS];
+    const TQ k0 = kq0[0], k1 = kq1[0];
+    const TQ g0n = S[L.vin + ip * VS + j0];
+    TQ g1n = 0;
+    if (!F64) g1n = S[L.vin + ip * VS + j1];
     if (affine) gcn = S[L.Dx + ip * VS + c];
     PF_FINE(11);
     const TQ u0 = rowsum(k0 * xc) + g0;
@@ -1070,8 +1121,10 @@ MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const L
     PF_FINE(14);
     xc = xn;
     if (lane < VS) S[xo + (i + 1) * VS + lane] = xn;
-    k0 = k0n; g0 = g0n; k1 = k1n; g1 = g1n; gc = gcn;
+    g0 = g0n; g1 = g1n; gc = gcn;
     shift<TQ, PD>(qa);
+#pragma unroll
+    for (int d = 0; d < KD; ++d) { kq0[d] = kq0[d + 1]; kq1[d] = kq1[d + 1]; }
   }
   __syncthreads();
 }
@@ -1092,7 +1145,7 @@ template <typename TQ> __device__ inline TQ pin_diag() { return sizeof(TQ) == 8 
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L PF_ARG, TQ* gscale = nullptr, P<TQ> mrows = nullptr,
+MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L PF_ARG, TQ* gscale = nullptr, P<TQ> mrows = nullptr,
                                       P<TQ> pstore = nullptr, int start = -1) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
@@ -1283,10 +1336,10 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
       TQ ex = tb - dot;
       if (affine) ex += qvi;                // stage gradient q_i enters the recursion directly
       pcol = c < NX ? ex : TQ(0);
-      S[L.K + i * KS + h * ABW + c] = kk;   // K[h][c] from the lane that holds it; columns 13..15 are the zero pad of the row operands
+      Kb[L.K + i * KS + h * ABW + c] = kk;   // K[h][c] from the lane that holds it; columns 13..15 are the zero pad of the row operands
       if (inv) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) S[L.Linv + i * 16 + vj * 4 + j] = y[j];
+        for (int j = 0; j < 4; ++j) Kb[L.Linv + i * 16 + vj * 4 + j] = y[j];
         S[L.vin + i * VS + vj] = (polish && ((pinb >> vj) & 1)) ? TQ(0) : -dot;
       }
     }
@@ -1336,12 +1389,22 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Ld
   return wave_min<int>(ok ? 1 : 0) != 0;   // all lanes agree on definiteness
 }
 
+#ifdef MPCQ_DUMP_AT
+template <typename TQ, typename PT> __device__ inline void dbg_dump(const DevModel<TQ>& m, int slot, PT base, int off, int n) {
+  if (!m.dbg) return;
+  double* d = m.dbg + (size_t)blockIdx.x * 4096 + slot;
+  for (int i = lane_id(); i < n; i += 64) d[i] = (double)base[off + i];
+}
+#define DBG_DUMP(at, slot, base, off, n) do { if (MPCQ_DUMP_AT == (at)) dbg_dump(m, slot, base, off, n); } while (0)
+#else
+#define DBG_DUMP(at, slot, base, off, n)
+#endif
 // ------------------------------------------------------------------ QP: IPM + polish
 // Mehrotra predictor-corrector iterations; every Newton system is one Riccati factorisation + two
 // vector sweeps.  Continues from the current (z, sl, su, ll, lu, dx, grad) until |r_d| <= tol*gm and
 // mu <= tol.  returns 0 converged / 1 NaN / 2 iteration cap / 4 stage Hessian not positive definite
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
+MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int status = 2;
   const int maxit = m.qp_max_iter;
@@ -1359,10 +1422,12 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, con
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    const bool fok = riccati_factor<C, false>(m, S, A, L PF_PASS);
+    const bool fok = riccati_factor<C, false>(m, S, A, Kb, L PF_PASS);
     PF_STOP(PF_FACTOR);
+    if (it == 0) { DBG_DUMP(2, 0, S, L.rt, nv); DBG_DUMP(2, 128, Kb, L.K, N * KS); DBG_DUMP(2, 2048, Kb, L.Linv, N * 16); DBG_DUMP(2, 3000, S, L.vin, N * VS); }
     if (!fok) { status = 4; break; }
-    PF_START(); riccati_forward<C>(m, S, A, L, L.dza PF_PASS); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dza PF_PASS); PF_STOP(PF_FWD);
+    if (it == 0) { DBG_DUMP(3, 0, S, L.dza, nv); DBG_DUMP(3, 128, S, L.Dx, (N + 1) * VS); }
     // Step lengths without divisions: alpha = min_i(-s_i / ds_i | ds_i < 0) = 1 / max_i(-ds_i / s_i), and every quotient by a
     // slack or a multiplier is a product with its reciprocal (v_rcp_f64 + two Newton steps instead of the ~35-instruction
     // IEEE division, 28 of which per input and iteration were 8 % of an iteration).
@@ -1394,8 +1459,10 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, con
       S[L.rho + i] = rd - rcl * rsl + rcu * rsu;
     }
     __syncthreads();
-    PF_START(); riccati_backward_vec<C>(m, S, A, L, false); PF_STOP(PF_BWD);
-    PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+    PF_START(); riccati_backward_vec<C>(m, S, A, Kb, L, false); PF_STOP(PF_BWD);
+    if (it == 0) { DBG_DUMP(4, 0, S, L.rho, nv); DBG_DUMP(4, 128, S, L.vin, N * VS); }
+    PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+    if (it == 0) { DBG_DUMP(5, 0, S, L.dz, nv); DBG_DUMP(5, 128, S, L.Dx, (N + 1) * VS); }
     TQ apinv = 1, adinv = 1;
     for (int i = tid; i < nv; i += 64) {
       const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
@@ -1438,6 +1505,7 @@ template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
   why = QPX_BUDGET;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
+  const P<TQ> Kb = C::GK ? G : S;   // where the gains live
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
     for (int i = tid; i < nv; i += 64) {
       S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
@@ -1513,13 +1581,13 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
       pf.acc[13] += (keep_p && top >= 0 && top < N - 1) ? top + 1 : N;   // stages this factorisation visits
       pf.acc[14] += 1;                                                    // factorisations
 #endif
-      const bool fok = riccati_factor<C, true, true>(m, S, A, L PF_PASS, &gfac, nact > 0 ? G + L.mrow : P<TQ>(nullptr), keep_p ? G + L.pst : P<TQ>(nullptr), top);
+      const bool fok = riccati_factor<C, true, true>(m, S, A, Kb, L PF_PASS, &gfac, nact > 0 ? G + L.mrow : P<TQ>(nullptr), keep_p ? G + L.pst : P<TQ>(nullptr), top);
       top = -1;
       PF_STOP(PF_FACTOR);
       if (!fok) { why = QPX_NUMERIC; return false; }
       gm = tmax(gm, tmax(TQ(1), gfac));   // a restarted factorisation sees only the stages it visits
       tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
-      PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+      PF_START(); riccati_forward<C, true>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
       // the sweep returns the minimiser itself: turn it into a step from the current point for the ratio test below
       for (int i = tid; i < nv; i += 64)
         if (S[L.act + i] == TQ(0)) S[L.dz + i] -= S[L.z + i];
@@ -1658,7 +1726,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
 // rollout and a gradient sweep first): used for TQ = float, where increments keep their accuracy while a from-scratch
 // affine solve would have to be refined again every time.
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
+MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
   why = QPX_BUDGET;
   bool fresh = false;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
@@ -1697,14 +1765,14 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, cons
       __syncthreads();
       PF_START();
       TQ gfac = 0;
-      const bool fok = riccati_factor<C, true, true>(m, S, A, L PF_PASS, &gfac);
+      const bool fok = riccati_factor<C, true, true>(m, S, A, Kb, L PF_PASS, &gfac);
       PF_STOP(PF_FACTOR);
       if (!fok) { why = QPX_NUMERIC; return false; }
       gm = tmax(TQ(1), gfac);
       tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
       tols = (sizeof(TQ) == 4 ? TQ(MPCQ_F32_TOLS) : TQ(64)) * m.eps * gm;
       refactor = false;
-      PF_START(); riccati_forward<C, true>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+      PF_START(); riccati_forward<C, true>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
       dx_done = true;
     } else if (full) {
       // the last pass took a full Newton step with an unchanged working set: the state trajectory is affine in z
@@ -1770,10 +1838,10 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, cons
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
     PF_START();
-    if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, L PF_PASS); PF_STOP(PF_FACTOR); if (!fok) { why = QPX_NUMERIC; return false; } }
-    else { riccati_backward_vec<C>(m, S, A, L, true); PF_STOP(PF_BWD); }
+    if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, Kb, L PF_PASS); PF_STOP(PF_FACTOR); if (!fok) { why = QPX_NUMERIC; return false; } }
+    else { riccati_backward_vec<C>(m, S, A, Kb, L, true); PF_STOP(PF_BWD); }
     refactor = false;
-    PF_START(); riccati_forward<C>(m, S, A, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
     }
     TQ alpha = 1;
     for (int i = tid; i < nv; i += 64) {
@@ -1825,6 +1893,7 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const 
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0, why = 0;
   TQ gm = 1;
+  const P<TQ> Kb = C::GK ? G : S;   // where the gains live
   // prev_iter: this quadrotor's previous return value (0: cold start).  Decimal fields (qp_iter of include/mpcq.h):
   //   passes + interior-point iterations | x 1000: the warm attempt was given up or skipped (fallback solve) |
   //   x 10000: flip mark | x 100000: why the warm attempt ended (QPX_*).
@@ -1840,7 +1909,7 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const 
   if (flipping) { wpasses = 1000; why = QPX_SKIPPED; }   // counts as a fallback solve
   if (prev_iter > 0 && warm_cap > 0) {
     if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap, why PF_PASS)
-                        : polish_incremental<C>(m, S, A, L, gm, wpasses, true, warm_cap, why PF_PASS)) {   // sets z = 0 and its own gradient scale
+                        : polish_incremental<C>(m, S, A, Kb, L, gm, wpasses, true, warm_cap, why PF_PASS)) {   // sets z = 0 and its own gradient scale
       *status = 0;
       return wpasses;
     }
@@ -1861,20 +1930,22 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const 
   gm = wave_max(gm);
   for (int i = tid; i < nv; i += 64) { S[L.ll + i] = m.ipm_mu0 * gm / S[L.sl + i]; S[L.lu + i] = m.ipm_mu0 * gm / S[L.su + i]; }
   __syncthreads();
-  st = ipm_run<C>(m, S, A, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+  DBG_DUMP(1, 0, S, L.z, nv); DBG_DUMP(1, 128, S, L.sl, nv); DBG_DUMP(1, 256, S, L.su, nv); DBG_DUMP(1, 384, S, L.ll, nv); DBG_DUMP(1, 512, S, L.lu, nv);
+  DBG_DUMP(1, 640, S, L.grad, N * VS); DBG_DUMP(1, 1024, S, L.dx, (N + 1) * VS); DBG_DUMP(1, 1536, A, L.AB, N * ABS > 2500 ? 2500 : N * ABS);
+  st = ipm_run<C>(m, S, A, Kb, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
   bool need_roll = true;
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
     int why2 = 0;
     if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, passes, false, m.polish_max, why2 PF_PASS)
-                        : polish_incremental<C>(m, S, A, L, gm, passes, false, m.polish_max, why2 PF_PASS)) need_roll = false;
+                        : polish_incremental<C>(m, S, A, Kb, L, gm, passes, false, m.polish_max, why2 PF_PASS)) need_roll = false;
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
       PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
       PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
-      st = ipm_run<C>(m, S, A, L, m.qp_tol, gm, it PF_PASS);
+      st = ipm_run<C>(m, S, A, Kb, L, m.qp_tol, gm, it PF_PASS);
     }
   }
   if (need_roll) { PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
@@ -1965,12 +2036,13 @@ __device__ inline int chunk_have(int len, int idx, int N, int skip) {
 #ifndef MPCQ_MIN_WAVES_PER_EU
 #define MPCQ_MIN_WAVES_PER_EU 1
 #endif
+// (compact-layout instances exist to put a second wave on a SIMD: at most 256 registers)
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-__global__ void __launch_bounds__(64, MPCQ_MIN_WAVES_PER_EU) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
+__global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_kernel(const DevModel<typename C::T> m, const DevState<typename C::T> st, const int mode) {
   const int tid = lane_id();
   const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
   const int b = st.order ? st.order[blockIdx.x] : (int)blockIdx.x;
-  const Lds L = lds_layout(N, nb, GAB ? 1 : 0);
+  const Lds L = lds_layout(N, nb, C::LAYOUT);
 #ifdef MPCQ_CHECKED
   if (tid == 0) *reinterpret_cast<int**>(smem_raw) = st.chk;   // where violations are recorded (ck_rec)
   if (tid == 0 && b == 0 && st.chk) { const unsigned long long pc = __builtin_amdgcn_s_getpc(); st.chk[9] = (int)(unsigned)pc; st.chk[10] = (int)(unsigned)(pc >> 32); }
@@ -1991,6 +2063,16 @@ __global__ void __launch_bounds__(64, MPCQ_MIN_WAVES_PER_EU) step_kernel(const D
   // own: instances are independent, so nothing forces the batch to wait for its slowest member every period.
   const int periods = C::RUN ? st.run_steps : 1;
   for (int period = 0; period < periods; ++period) {
+#ifdef MPCQ_TRACE_NAN   // reproducer builds only (tools/repro_codegen): which phase of which period first holds a non-finite value
+  auto nonfinite = [&](auto base, int off, int n) {
+    int bad = 0;
+    for (int i = tid; i < n; i += 64) { const double v = (double)base[off + i]; if (!(fabs(v) < 1e300)) bad = 1; }
+    return (unsigned long long)wave_max(bad);
+  };
+  auto trace = [&](int cp, unsigned long long bits) {
+    if (tid == 0 && st.prof && period < 4) st.prof[(size_t)b * PF_N + 4 * period + cp] = bits | (1ull << 63);
+  };
+#endif
   // ---- load persistent state (lane-contiguous records) and form the QP data in double.  All global
   //      loads of a block are issued before the first use so their latencies overlap.
   const P<double> gX = mk(st.X + (size_t)b * (N + 1) * NX, (N + 1) * NX, CK_X);
@@ -2049,9 +2131,11 @@ __global__ void __launch_bounds__(64, MPCQ_MIN_WAVES_PER_EU) step_kernel(const D
     const int i = it >> 2, k = it & 3;
     const double u = gU[it];
     D[L.U + it] = u;
-    S[L.r0 + it] = (TQ)(m.h * m.W[NX + k] * (u - uref(i, k)));
-    S[L.lb + it] = (TQ)(m.ulb[k] - u);
-    S[L.ub + it] = (TQ)(m.uub[k] - u);
+    if (!C::GK) {   // (compact layout: these three share the space of the shooting records and are written behind the shooting)
+      S[L.r0 + it] = (TQ)(m.h * m.W[NX + k] * (u - uref(i, k)));
+      S[L.lb + it] = (TQ)(m.ulb[k] - u);
+      S[L.ub + it] = (TQ)(m.uub[k] - u);
+    }
   }
   if (tid < NX && !meas_from_plant) D[L.x0 + tid] = xm;
   // the post phase's reads of the persistent state travel with the loads of this phase (three serial global round trips
@@ -2097,6 +2181,10 @@ __global__ void __launch_bounds__(64, MPCQ_MIN_WAVES_PER_EU) step_kernel(const D
   }
   __syncthreads();
   PF_STOP(PF_LOAD);
+#ifdef MPCQ_TRACE_NAN
+  trace(0, nonfinite(D, L.X, (N + 1) * NX) | nonfinite(D, L.U, nv) << 1 | nonfinite(D, L.x0, NX) << 2 | nonfinite(A, L.qv, (N + 1) * VS) << 3 |
+               (gp ? nonfinite(S, L.alpha, 3 * nb) : 0ull) << 4 | (unsigned long long)(unsigned)idx << 32);
+#endif
   // ---- 1. shooting
   shoot_states<C>(m, D, S, A, L, gp);
   __syncthreads();
@@ -2104,8 +2192,20 @@ __global__ void __launch_bounds__(64, MPCQ_MIN_WAVES_PER_EU) step_kernel(const D
   shoot_sens<C>(m, S, A, L);
   __syncthreads();
   PF_STOP(PF_SHOOT_S);   // shooting records (union region) are dead from here on
+#ifdef MPCQ_TRACE_NAN
+  trace(1, nonfinite(A, L.c, N * VS) | nonfinite(A, L.AB, N * ABS) << 1);
+#endif
   if (tid < VS) { S[L.dx + tid] = 0; A[L.AB + N * ABS + tid] = 0; S[L.zb + tid] = 0; }
   for (int it = tid; it < N * VS; it += 64) S[L.vin + it] = 0;
+  if (C::GK) {   // r0 = R (U_i - uref_i), bounds: the same expressions as in the load phase, from the iterate in LDS
+    for (int it = tid; it < nv; it += 64) {
+      const int i = it >> 2, k = it & 3;
+      const double u = D[L.U + it];
+      S[L.r0 + it] = (TQ)(m.h * m.W[NX + k] * (u - uref(i, k)));
+      S[L.lb + it] = (TQ)(m.ulb[k] - u);
+      S[L.ub + it] = (TQ)(m.uub[k] - u);
+    }
+  }
   __syncthreads();
   if (tid < NX) S[L.dx + o2i(tid)] = (TQ)(D[L.x0 + tid] - D[L.X + tid]);   // dx_0 = x_meas - X_0 (lbx = ubx = x_init)
   __syncthreads();
@@ -2113,6 +2213,9 @@ __global__ void __launch_bounds__(64, MPCQ_MIN_WAVES_PER_EU) step_kernel(const D
   int status = 0;
   const int prev_iter = st.qp_iter[b];
   const int iters = solve_qp<C>(m, S, A, G, L, &status, prev_iter PF_PASS);
+#ifdef MPCQ_TRACE_NAN
+  trace(2, nonfinite(S, L.z, nv) | nonfinite(S, L.dx, (N + 1) * VS) << 1 | (unsigned long long)(status & 0xff) << 8 | (unsigned long long)(unsigned)iters << 32);
+#endif
   PF_START();
   // ---- 3. full step (iterate accumulated in double).  A step that is not finite (a QP that broke down: only seen
   //      with the fp32 QP on infeasible references) is not taken: the iterate and the control of the previous period
@@ -2169,6 +2272,9 @@ __global__ void __launch_bounds__(64, MPCQ_MIN_WAVES_PER_EU) step_kernel(const D
   // (include/mpcq.h, MPCQ_SOLVE_LOW_ACCURACY): taken, but reported
   if (sizeof(TQ) == 4 && status == 0 && ((iters / 1000) % 10 != 0 || prev_iter == 0)) status = 8;   // fallback solve or cold start
   if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; }
+#ifdef MPCQ_TRACE_NAN
+  trace(3, (unsigned long long)(status & 0xff) | (unsigned long long)unsound << 8 | (unsigned long long)bad << 9 | (unsigned long long)(unsigned)prev_iter << 32);
+#endif
   if (tid < NU) {
     gW[tid] = D[L.U + tid];
     if (st.w_ext) st.w_ext[(size_t)b * NU + tid] = D[L.U + tid];

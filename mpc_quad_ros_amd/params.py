@@ -77,7 +77,7 @@ class CTuning(ctypes.Structure):
     ]
 
 
-STAGE_MEM = {"auto": 0, "lds": 1, "global": 2}
+STAGE_MEM = {"auto": 0, "lds": 1, "global": 2, "compact": 3}
 
 
 class CConfig(ctypes.Structure):

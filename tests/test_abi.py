@@ -48,6 +48,23 @@ def test_config_struct_matches_header_order():
     assert names == [f[0] for f in CTuning._fields_]
 
 
+def test_code_objects_pass_the_exec_prologue_check():
+    """Round 4 root-caused the code-generation-dependent wrong results of rounds 1-3 (tools/repro_codegen/README.md): ROCm 7.2's
+    register allocator can place VGPR -> AGPR spill copies in front of the EXEC restore of a control-flow join, where they execute
+    for no lane.  tools/check_exec_prologue.py finds that pattern in a code object: it must flag the committed excerpt of the
+    failing kernel, and every kernel of the in-tree libmpcq.so must be clean (the Makefile enforces the same at build time)."""
+    import subprocess
+    import sys
+    chk = os.path.join(ROOT, "tools", "check_exec_prologue.py")
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no ROCm LLVM tools on this runner")
+    bad = subprocess.run([sys.executable, chk, os.path.join(ROOT, "tools", "repro_codegen", "isa_excerpt_BB10_117.s")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "EXEC = 0" in bad.stdout and "v_accvgpr_write_b32" in bad.stdout, bad.stdout
+    good = subprocess.run([sys.executable, chk, _lib.DEFAULT_LIB], capture_output=True, text=True)
+    assert good.returncode == 0, good.stdout[-2000:]
+    assert good.stdout.count("clean") >= 20          # every step-kernel instance of the library was looked at
+
+
 def test_no_gpu_fails_loudly():
     if os.path.exists("/dev/kfd"):
         pytest.skip("GPU present")

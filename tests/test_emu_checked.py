@@ -75,13 +75,13 @@ e = Engine(EngineConfig(batch=1, N=5), lib_path=%r)
 assert b"CHECKED" in e.lib.mpcq_version()
 traj = np.zeros((1, 40, 13)); traj[:, :, 3] = 1.0
 e.set_trajectories(traj)
-e.set_state(idx=np.array([-7]))          # a corrupted cursor: rows idx + j skip < 0
+e.set_state(idx=np.array([-7]))          # a corrupted cursor: rows idx + j skip < 0 (the library refuses it unless told not to, see env below)
 try:
     e.step(traj[:, 0].copy())
 except _lib.MpcqError as ex:
     print("REPORTED", ex)
 """ % (HERE, os.path.dirname(HERE), LIB)
-    env = dict(os.environ, LD_PRELOAD=checked_lib)
+    env = dict(os.environ, LD_PRELOAD=checked_lib, MPCQ_TUNING="1", MPCQ_SKIP_STATE_CHECKS="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     assert "REPORTED" in out.stdout.decode() and "region tag 6" in out.stdout.decode(), out.stdout.decode()

@@ -107,6 +107,18 @@ def test_emu_lane_order_independent_closed_loop():
     assert eval(out) == fwd
 
 
+def test_emu_compact_layout_against_oracle():
+    """The compact layout of large batches (lds_layout gab = 2: Riccati gains in the per-instance global record, fetched ahead like
+    the stage records; r0 / lb / ub written behind the shooting into the space of its records): warm active-set solves,
+    interior-point fallbacks and flip-marked quadrotors against the oracle."""
+    make_c = lambda cfg: make(dataclasses.replace(cfg, tune=dict(stage_mem="compact")))
+    assert pc.case_teacher_forced_log(make_c, "log_trajectory_v15_a5_gp2.npz", 8) < 1e-8
+    worst, hist, failed = pc.case_saturating_references(make_c, B=2, K=10)
+    assert failed == 0 and worst < 1e-7
+    from mpc_quad_ros_amd.engine import qp_fallback
+    assert any(qp_fallback(v) for v in hist)
+
+
 def test_emu_block_order_is_cost_sorted_and_changes_nothing():
     """mpcq::order_kernel (launch order of a lockstep period, large batches): a permutation inside the classes p mod 8, every
     class in ascending cost bin of the previous period's qp_iter (bin 0 = predicted most expensive), and the results of the

@@ -87,11 +87,22 @@ def _argument_errors(lib):
     with pytest.raises(_lib.MpcqError):
         e.set_trajectories(np.zeros((1, 10, 13)), np.array([11]))
     # solver tuning is validated, not read from the environment
-    for bad in (dict(warm_max=-3), dict(warm_max=1000), dict(pin_ratio=-1.0), dict(ipm_mu0=5.0), dict(ipm_margin=0.7), dict(stage_mem=3),
-                dict(flip_max=-2), dict(ipm_tol=float("nan"))):
+    for bad in (dict(warm_max=-3), dict(warm_max=1000), dict(pin_ratio=-1.0), dict(ipm_mu0=5.0), dict(ipm_margin=0.7), dict(stage_mem=4),
+                dict(flip_max=-2), dict(ipm_tol=float("nan")), dict(block_order=3), dict(reserved0=1)):
         with pytest.raises(_lib.MpcqError, match="tune"):
             Engine(EngineConfig(batch=1, N=5, tune=bad), lib_path=lib)
     Engine(EngineConfig(batch=1, N=5, tune=dict(warm_max=8, flip_max=-1, abort_pins=-1, stage_mem="global", pin_ratio=0.5)), lib_path=lib).close()
+    Engine(EngineConfig(batch=1, N=5, tune=dict(stage_mem="compact", block_order=2)), lib_path=lib).close()
+    # a restored checkpoint is validated (advisor finding of round 3: a negative cursor used to reach the kernel)
+    traj = np.zeros((1, 10, 13)); traj[:, :, 3] = 1.0
+    e.set_trajectories(traj)
+    for bad_state, what in ((dict(idx=np.array([-7])), "cursor"), (dict(has_prev=np.array([2])), "has_prev")):
+        with pytest.raises(_lib.MpcqError, match=what):
+            e.set_state(**bad_state)
+    e.set_state(idx=np.array([14]), has_prev=np.array([1]))      # at or beyond the end is a valid cursor (the chunk repeats the last row)
+    for bad_sol, what in ((dict(qp_iter=np.array([-1])), "qp_iter"), (dict(qp_iter=np.array([1000000])), "qp_iter"), (dict(finished=np.array([3])), "finished")):
+        with pytest.raises(_lib.MpcqError, match=what):
+            e.set_solver_state(**bad_sol)
     with pytest.raises(ValueError, match="unknown tuning field"):
         EngineConfig(batch=1, N=5, tune=dict(warm=3)).to_c()
     _versioned_create(lib)

@@ -93,9 +93,10 @@ def test_config2_shape_against_oracle():
 @pytest.mark.parametrize("shape", [(20, 10, 64, 25), (20, 20, 64, 25), (50, 50, 12, 12)], ids=["N20nb10", "N20nb20", "N50nb50"])
 @pytest.mark.parametrize("precision", [0, 1])
 def test_kernel_variants_agree(precision, shape):
-    """The four step-kernel variants of one precision (stage records in LDS / global memory, shape-specialised -O3 /
-    any-shape -O2 instantiation) are the same algorithm: identical working sets, controls equal to rounding.  Every
-    shape that has a specialised instance (mpcq_spec.hip: BASELINE configs[1], [2], [4]) is covered."""
+    """The six step-kernel variants of one precision (working set all in LDS / stage records in global memory / compact:
+    gains in global memory too, 256 registers; each as the shape-specialised -O3 and the any-shape -O2 instantiation) are the
+    same algorithm: identical working sets, controls equal to rounding.  Every shape that has a specialised instance
+    (mpcq_spec.hip: BASELINE configs[1], [2], [4]) is covered."""
     from mpc_quad_ros_amd import _lib
     from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
     from mpc_quad_ros_amd.trajectories import swarm_trajectories
@@ -103,7 +104,7 @@ def test_kernel_variants_agree(precision, shape):
     traj, lens = swarm_trajectories(11, 0, B)
     x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
     out = {}
-    for mem in ("lds", "global"):
+    for mem in ("lds", "global", "compact"):
         for generic in (False, True):
             try:
                 e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision,
@@ -128,6 +129,9 @@ def test_kernel_variants_agree(precision, shape):
     if precision == 0 and ("lds", True) in out:   # same arithmetic, two instantiations: agreement far below the solver tolerances
         assert pc.rel_err(out[("lds", True)], out[("global", True)]) < 1e-12
         assert pc.rel_err(out[("lds", False)], out[("global", False)]) < 1e-12
+    if precision == 0:                            # the compact layout moves data, not arithmetic
+        assert pc.rel_err(out[("compact", True)], out[("global", True)]) < 1e-12
+        assert pc.rel_err(out[("compact", False)], out[("global", False)]) < 1e-12
 
 
 @pytest.mark.parametrize("name,K", [
@@ -343,6 +347,67 @@ def test_free_running_equals_lockstep_every_instance(precision, shape, start):
         st_a, st_b = out[0][-1], out[1][-1]     # amplified by the closed loop -- compared through the tracking statistic and the cursors
         assert np.array_equal(out[0][6], out[1][6])
         assert np.allclose(st_a[:3], st_b[:3], rtol=0.1, atol=1e-6) and out[0][1].min() >= 0.0 and out[1][1].max() <= 1.0
+
+
+@pytest.mark.parametrize("shape", [(20, 10), (20, 20), (50, 50), (10, 10)], ids=["N20nb10", "N20nb20", "N50nb50", "N10nb10-any-shape"])
+def test_compact_layout_free_running_equals_lockstep(shape):
+    """The compact layout (large batches: six quadrotors per CU instead of four in fp64 at N = 20) as lockstep launches of the
+    shape-specialised instance and as one persistent launch of the any-shape instance, 150 periods into the flights: bit for
+    bit the same, and bit for bit what the default layout of this batch size gives (plant states, controls, iterate, RGP
+    posterior, cursors, tracking statistic)."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    N, nb = shape
+    B, pre, K = (256, 150, 24) if N <= 20 else (64, 40, 12)
+    traj, lens = swarm_trajectories(13, 0, B)
+    lens = lens.copy(); lens[0] = pre + 6                # one trajectory ends inside the window
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    out = []
+    for mode, tune in (("sim_steps", dict(stage_mem="compact")), ("sim_run", dict(stage_mem="compact")), ("sim_steps", None)):
+        e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), tune=tune))
+        e.set_trajectories(traj, lens)
+        e.sim_reset(x0)
+        e.sim_steps(pre, 2, 5e-3)
+        for _ in range(3):
+            getattr(e, mode)(K // 3, 2, 5e-3)
+        assert ((e.get_status() & 7) == 0).all()
+        st = e.get_state()
+        out.append((*e.sim_get_state(), st["X"], st["U"], st["mu"], st["C"], st["idx"], e.get_tracking_stats(), e.get_qp_iter()))
+        e.close()
+    for a, b, c in zip(*out):
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, c)
+
+
+def test_matrix_cores_off_build_is_bit_identical():
+    """BASELINE configs[4] ablation, MFMA on / off: libmpcq_nomfma.so (csrc/Makefile `variant NAME=nomfma`, the tile products
+    through ds_bpermute + vector FMAs in the instruction's own accumulation order) against the product at N = 50 / nb = 50:
+    12 quadrotors x 12 closed-loop periods from a cold start (interior-point solves, working-set passes), both precisions --
+    bit for bit.  Skipped when the ablation build is not in the tree."""
+    import os
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    nomfma = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpc_quad_ros_amd", "libmpcq_nomfma.so")
+    if not os.path.exists(nomfma):
+        pytest.skip("libmpcq_nomfma.so not built (make -C mpc_quad_ros_amd/csrc variant NAME=nomfma ...)")
+    B, N, nb, K = 12, 50, 50, 12
+    traj, lens = swarm_trajectories(21, 0, B)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    for precision in (0, 1):
+        out = []
+        for lib in (None, nomfma):
+            e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), precision=precision), lib_path=lib)
+            e.set_trajectories(traj, lens); e.sim_reset(x0)
+            e.sim_steps(1, 2, 5e-3)
+            first = e.get_qp_iter()
+            e.sim_steps(K - 1, 2, 5e-3)
+            assert ((e.get_status() & 7) == 0).all()
+            st = e.get_state()
+            out.append((*e.sim_get_state(), st["X"], st["U"], st["mu"], st["C"], e.get_qp_iter(), first))
+            e.close()
+        for k, (a, b) in enumerate(zip(*out)):
+            assert np.array_equal(a, b), (precision, k)
+        assert (out[0][-1] % 1000 > 1).all()        # the cold-start solves went through the interior point (several factorisations each)
 
 
 def test_config2_full_size():

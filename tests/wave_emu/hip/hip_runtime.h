@@ -242,6 +242,7 @@ hipError_t hipEventSynchronize(hipEvent_t);
 hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t);
 hipError_t hipGetLastError();
 hipError_t hipFuncSetAttribute(const void*, int, int);
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int*, const void*, int, size_t);
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   emu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })

@@ -3,8 +3,8 @@
 fp64 / fp32 arithmetic, bf16 STORAGE of the records (fp32 arithmetic) and the matrix cores switched off, each as
 (a) worst relative control deviation against the fp64 CPU oracle over a host-driven closed loop of 64 quadrotors x 60
 control periods and (b) lockstep control steps/s at B = 4096.  Needs the ablation builds:
-  make -C mpc_quad_ros_amd/csrc variant NAME=nomfma EXTRA=-DMPCQ_NO_MFMA
-  make -C mpc_quad_ros_amd/csrc variant NAME=bf16 EXTRA=-DMPCQ_BF16_RECORDS
+  make -C mpc_quad_ros_amd/csrc variant NAME=nomfma SHAPES=50_50 EXTRA="-DMPCQ_NO_MFMA '-DMPCQ_SHAPE_LIST(X)=X(50,50)'"
+  make -C mpc_quad_ros_amd/csrc variant NAME=bf16 SHAPES=50_50 EXTRA="-DMPCQ_BF16_RECORDS '-DMPCQ_SHAPE_LIST(X)=X(50,50)'"
 The oracle is used here as the checker only (tools/ is not the product)."""
 import json, os, sys, time
 import numpy as np
@@ -32,11 +32,11 @@ def parity(name, precision):
     worst, typ, failed, changes = 0.0, [], 0, 0
     for k in range(KP):
         w, _ = e.step(x); wo, _ = o.step(x)
-        ok = e.get_status() == 0
+        ok = (e.get_status() & 7) == 0          # (MPCQ_SOLVE_LOW_ACCURACY, 8, is a warning of the fp32 mode: counted as solved here)
         failed += int((~ok).sum())
         changes += int(((e.get_qp_iter() % 1000) > 1).sum())
         err = np.abs(w - wo).max(axis=1) / np.maximum(np.abs(wo).max(axis=1), 1e-2)      # per quadrotor
-        worst = max(worst, float(err[ok].max())); typ.append(float(np.median(err)))
+        worst = max(worst, float(err[ok].max()) if ok.any() else 0.0); typ.append(float(np.median(err)))
         x = o.plant_control_period(x, wo, 0.01, 5e-3)[0]
     return dict(worst_rel_dev=worst, median_rel_dev=float(np.median(typ)), failed_solves=failed, quad_steps_with_working_set_change=changes)
 
@@ -48,16 +48,15 @@ def throughput(name, precision):
     e.sim_steps(60, 2, 5e-3)
     t0 = time.perf_counter(); e.sim_steps(KT, 2, 5e-3); e.synchronize(); t1 = time.perf_counter()
     kt, kl = e.get_kernel_time()
-    return dict(steps_per_s=BT * KT / (t1 - t0), ms_per_step=1e3 * (t1 - t0) / KT, kernel_avg_ms=1e3 * kt / max(kl, 1), failed=int((e.get_status() != 0).sum()))
+    return dict(steps_per_s=BT * KT / (t1 - t0), ms_per_step=1e3 * (t1 - t0) / KT, kernel_avg_ms=1e3 * kt / max(kl, 1), failed=int(((e.get_status() & 7) != 0).sum()))
 
 
 rows = []
 for label, name, precision in [("fp64", "product", 0), ("fp32", "product", 1), ("fp32 arithmetic, bf16 storage of records + RGP state", "bf16", 1),
                                ("fp64, matrix cores off", "nomfma", 0), ("fp32, matrix cores off", "nomfma", 1),
-                               ("fp64, sweeps as tiles on the matrix cores", "mfmasweeps", 0), ("fp32, sweeps as tiles on the matrix cores", "mfmasweeps", 1)]:
+]:
     if name != "product" and not os.path.exists(lib(name)):
         print("skip", label, "(build missing)"); continue
-    os.environ["MPCQ_PIN_RATIO"] = "1" if precision == 1 else "0.2"   # the defaults, spelled out: variant builds may predate them
     r = dict(config=label, N=N, nb=NB)
     r["parity"] = parity(name, precision) if BP else None
     r["throughput"] = throughput(name, precision) if BT else None

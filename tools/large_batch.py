@@ -15,10 +15,17 @@ from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspac
 B, N, nb, pre, K = (int(v) for v in (sys.argv[1:6] + ["8192", "20", "10", "600", "40"][len(sys.argv) - 1:]))
 refs = bench.workload(2026, 0, B, pre + K + 30)
 out = {"B": B, "N": N, "nb": nb, "preroll": pre, "steps": K, "runs": []}
-for name, tune in (("identity order", dict(block_order=1)), ("cost-sorted order", dict(block_order=2))):
+VARIANTS = {"identity": ("identity order", dict(block_order=1)), "sorted": ("cost-sorted order", dict(block_order=2)),
+            "global": ("layout: stage records in global memory, cost-sorted order", dict(stage_mem=2)),
+            "compact": ("layout: compact (gains in global memory, 256 registers), cost-sorted order", dict(stage_mem=3))}
+which = os.environ.get("LB_VARIANTS", "identity,sorted").split(",")
+for name, tune in (VARIANTS[w] for w in which):
     e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), tune=tune))
     e.set_trajectories(*refs); e.sim_reset(np.tile(bench.X0, (B, 1)))
-    e.sim_run(pre, 2, 5e-3)
+    if os.environ.get("LB_PREROLL_LOCKSTEP"):      # (profiler runs: no long persistent launch under counter collection)
+        e.sim_steps(pre, 2, 5e-3)
+    else:
+        e.sim_run(pre, 2, 5e-3)
     e.sim_steps(5, 2, 5e-3)
     e.synchronize()
     t0 = time.perf_counter()
@@ -33,5 +40,5 @@ for name, tune in (("identity order", dict(block_order=1)), ("cost-sorted order"
                         "kernel_min_ms": 1e3 * kmin, "kernel_max_ms": 1e3 * kmax, "mean_passes": float(qp_passes(its).mean()),
                         "fallbacks_last": int(qp_fallback(its).sum()), "digest": float(np.sum(x) + np.sum(w))})
     e.close()
-out["bitwise_equal"] = out["runs"][0]["digest"] == out["runs"][1]["digest"]
+out["bitwise_equal"] = all(r["digest"] == out["runs"][0]["digest"] for r in out["runs"])
 print(json.dumps(out))
