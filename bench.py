@@ -51,6 +51,35 @@ def algorithmic_flops(N, nb, passes):
 
 
 PREROLL = 600                 # un-timed control periods before the warm-up (see --preroll)
+NONQP_CHAIN_US = 33.7         # load + shooting + full step + post phase of one quadrotor at their MEASURED cost (80.9 k cycles at 2.4 GHz,
+                              # profiles/r3_phase_cycles.txt): not floored, so latency_roofline.frac errs on the high side
+
+
+def latency_roofline(e, n_sub, N, launches=20):
+    """What bounds a lockstep launch is not bytes but the dependent instruction chain of its slowest quadrotor.  Floor of that
+    chain: (factorisations x N stages x the measured latency of one factorisation stage's dependent chain) + (sweeps x N x the
+    measured chain of one sweep stage) -- both from tools/microbench/chain_floor.hip (registers only, nothing but the chain;
+    profiles/r4_chain_floor.json) -- + the non-QP phases at their measured cost.  `launches` further lockstep periods, one call
+    each, with the work counters (mpcq_get_qp_work) and the launch time read back after every one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r4_chain_floor.json")) as fh:
+            fl = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    floor, got, slow_fac = [], [], []
+    for _ in range(launches):
+        e.sim_steps(1, n_sub, 5e-3)
+        kt, _kl = e.get_kernel_time()
+        fac, swp = e.get_qp_work()
+        chain_ns = (fac * fl["factor_stage_chain_ns"] + swp * fl["sweep_stage_chain_ns"]) * N
+        floor.append(float(chain_ns.max()) * 1e-6 + NONQP_CHAIN_US * 1e-3)
+        got.append(1e3 * kt)
+        slow_fac.append(int(fac[np.argmax(chain_ns)]))
+    return {"bound": "dependent-chain latency of the slowest quadrotor of a launch", "floor_ms": float(np.mean(floor)), "achieved_ms": float(np.mean(got)),
+            "frac": float(np.mean(floor) / np.mean(got)), "launches": launches, "slowest_quad_factorisations_mean": float(np.mean(slow_fac)),
+            "factor_stage_chain_ns": fl["factor_stage_chain_ns"], "sweep_stage_chain_ns": fl["sweep_stage_chain_ns"], "non_qp_phases_us_measured": NONQP_CHAIN_US,
+            "note": "floor = chain latencies measured in isolation (registers only, one wavefront per SIMD); the product's stage additionally loads its "
+                    "operands, hands rows over through LDS, stores gains / cost-to-go and carries ~4x the instructions of the bare chain"}
 
 
 def workload(seed, first_index, B, periods):
@@ -424,7 +453,8 @@ def main():
     prec = PRECISION_F64 if args.precision == "f64" else PRECISION_F32
     itemsize = 8 if prec == PRECISION_F64 else 4
     STEADY = args.steady if world == 1 else 0          # further periods on the same engine behind the timed region
-    periods = args.preroll + args.warmup + args.steps + STEADY
+    LAT = 20 if STEADY else 0                          # lockstep periods of the latency_roofline leg (one call each, counters read back)
+    periods = args.preroll + args.warmup + args.steps + STEADY + LAT
     headline = (B, N, nb) == (1024, 20, 10)
     legs = world == 1 and not args.no_configs and headline
     swarm = not args.no_configs and headline           # configs[3]: 8192 quadrotors on every rank, at every world size
@@ -496,6 +526,9 @@ def main():
                   "note": f"the {STEADY} control periods that follow the timed region, same engine: the representative lockstep rate of this workload "
                           "(`value` above is the driver's window; its launches hold more or fewer saturated quadrotors by chance)"}
 
+    lat = latency_roofline(e, n_sub, N, LAT) if LAT else None
+    if lat is None:
+        LAT = 0
     # ---- configs[3]-shaped leg on every rank: 8192 quadrotors per GPU (65 536 over 8), same pre-roll as the headline
     swarm_out = None
     if swarm:
@@ -571,6 +604,8 @@ def main():
         }
         if steady is not None:
             out["steady_state"] = steady
+        if lat is not None:
+            out["latency_roofline"] = lat
         if swarm_out is not None:
             out["swarm"] = swarm_out
         # HBM bytes per launch from rocprofv3 --pmc passes (profiles/README.md): attached only when the profile was taken on
@@ -611,13 +646,14 @@ def main():
             e3.sim_run(args.preroll + args.warmup, n_sub, 5e-3)
             e3.synchronize()
             ta = time.perf_counter()
-            e3.sim_run(args.steps + STEADY, n_sub, 5e-3)
+            e3.sim_run(args.steps + STEADY + LAT, n_sub, 5e-3)
             e3.synchronize()
             tb = time.perf_counter()
             k3, _l3 = e3.get_kernel_time()
             x_run, w_run = e3.sim_get_state()
-            out["free_running"] = {"value": B * (args.steps + STEADY) / (tb - ta), "unit": "control steps/s", "dtype": args.precision, "steps": args.steps + STEADY,
-                                   "ms_per_step": 1e3 * (tb - ta) / (args.steps + STEADY), "kernel_ms_per_step": 1e3 * k3 / (args.steps + STEADY),
+            KF = args.steps + STEADY + LAT
+            out["free_running"] = {"value": B * KF / (tb - ta), "unit": "control steps/s", "dtype": args.precision, "steps": KF,
+                                   "ms_per_step": 1e3 * (tb - ta) / KF, "kernel_ms_per_step": 1e3 * k3 / KF,
                                    "launches": 1, "bitwise_equal_to_lockstep": bool(np.array_equal(x_run, x_lock) and np.array_equal(w_run, w_lock)),
                                    "note": "one persistent launch over the timed AND the steady-state periods, each workgroup advances its quadrotor through all of them "
                                            "(step + plant) on its own; identical arithmetic and results, no per-period wait for the "

@@ -45,7 +45,8 @@ typedef enum mpcq_status {
 #define MPCQ_SOLVE_MAXITER 2
 #define MPCQ_SOLVE_QP_FAILURE 4
 #define MPCQ_SOLVE_LOW_ACCURACY 8 /* MPCQ_PRECISION_F32 only: the step was taken, but its QP went through the interior-point fallback in
-                                     float -- outside the 1e-4 control budget (a warning, not a failure: mpcq_get_tracking_stats out[4] does not count it) */
+                                     float or started cold -- outside the 1e-4 control budget, measured bounds at MPCQ_PRECISION_F32 below
+                                     (a warning, not a failure: mpcq_get_tracking_stats out[4] does not count it) */
 
 /* mpcq_config.flags.  MPCQ_FLAG_STATIC_GP: the GP in the model is a static one (use_gp = 1, gpe.type == "GP",
  * src/quad_opt.py:228-236 with src/gp/GP.py:136-175): basis = its training inputs, theta = (L, sigma_f,
@@ -55,9 +56,16 @@ typedef enum mpcq_status {
 
 /* MPCQ_PRECISION_F64 (default): the reference's own arithmetic; <= 1e-7 relative control deviation from the fp64 oracle.
  * MPCQ_PRECISION_F32: EXPERIMENTAL fast mode (model evaluation, sensitivities and QP solve in float; iterate, measurement
- * and QP data differences stay double).  It meets the 1e-4 budget on solves that succeed from their warm start; a solve
- * that went through the interior point ((qp_iter / 1000) % 10 != 0) is only good to ~1e-3 (worse on references that keep
- * most inputs saturated) and is reported as such: status MPCQ_SOLVE_LOW_ACCURACY instead of 0. */
+ * and QP data differences stay double).  It does NOT hold the 1e-4 budget without exceptions; what the tests measure
+ * (tests/test_gpu_parity.py, teacher-forced against the fp64 oracle, relative control deviation):
+ *   - solves reported with status 0 (solved from their warm start): <= 1e-4 on the six reference logs and on swarms started
+ *     from hover at N = 20 and N = 50 (observed <= 2.4e-5); up to 2.1e-4 at N = 50 / nb = 50 started in flight with rotors
+ *     saturated at zero thrust (asserted < 1e-3 there);
+ *   - solves that went through the interior point in float ((qp_iter / 1000) % 10 != 0) AND cold-start solves (first step
+ *     after create / reset) are reported with status MPCQ_SOLVE_LOW_ACCURACY instead of 0: up to 1.2e-3 on the logs
+ *     (asserted < 5e-3, and at most max(6, K/12) flagged steps of a K-step log outside 1e-4), 1e-2 .. 0.2 where most inputs stay
+ *     saturated (asserted < 0.5, and < 50 % of the steps flagged).
+ *   The step is taken in every case; mpcq_get_tracking_stats out[4] does not count flagged steps as failures. */
 #define MPCQ_PRECISION_F64 0
 #define MPCQ_PRECISION_F32 1
 
@@ -155,6 +163,10 @@ int mpcq_get_status(mpcq_engine* e, int32_t* out);               /* solve() stat
  * on/off their bounds (the next solve skips the warm attempt); qp_iter / 100000: why the warm attempt ended
  * (MPCQ_WARM_*), 0 when it succeeded or there was none (cold start). */
 int mpcq_get_qp_iter(mpcq_engine* e, int32_t* out);
+/* What the last solve of every quadrotor executed, out [B]: Riccati factorisations (bits 0..15; resumed ones count as whole)
+ * | matrix-vector sweeps over the horizon (bits 16..31).  The dependent chains of these are what a lockstep launch lasts
+ * (bench.py `latency_roofline`).  acados reports sqp_iter / qp_iter through get_stats (src/quad_opt.py:337 reads time_tot only). */
+int mpcq_get_qp_work(mpcq_engine* e, int32_t* out);
 #define MPCQ_WARM_BUDGET 1    /* pass budget (warm_max / warm_retry) exhausted */
 #define MPCQ_WARM_PINS 2      /* first pass pinned >= abort_pins inputs */
 #define MPCQ_WARM_WRONG 3     /* a multiplier check found >= abort_wrong wrong signs */

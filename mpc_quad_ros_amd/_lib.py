@@ -31,6 +31,7 @@ SYMBOLS = [
     ("mpcq_get_cost", ctypes.c_int, [_vp, _dp]),
     ("mpcq_get_status", ctypes.c_int, [_vp, _ip]),
     ("mpcq_get_qp_iter", ctypes.c_int, [_vp, _ip]),
+    ("mpcq_get_qp_work", ctypes.c_int, [_vp, _ip]),
     ("mpcq_get_stats", ctypes.c_int, [_vp, _dp]),
     ("mpcq_predict_nominal", ctypes.c_int, [_vp, _dp, _dp, ctypes.c_double, _dp]),
     ("mpcq_rgp_regress", ctypes.c_int, [_vp, _dp, _dp]),

@@ -223,7 +223,7 @@ struct EngineT : mpcq_engine {
 
   ~EngineT() override {
     DeviceGuard guard(cfg.device);
-    void* ptrs[] = {st.chk, st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
+    void* ptrs[] = {st.qp_work, st.chk, st.finished, d_cmd, st.stage, st.X, st.U, st.mu, st.C, st.xpp, st.yref, st.yrefN, st.w, st.xpred, st.cost, st.stats, st.has_prev, st.idx,
                     st.status, st.qp_iter, d_basis, d_Kxinv, d_Kx, d_xin, d_uin, d_tmp, d_traj, d_xs, d_vb, d_ad, d_tlen, d_stats5, d_order};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
@@ -368,6 +368,7 @@ struct EngineT : mpcq_engine {
     if ((rc = dalloc(st.idx, Bz))) return rc;
     if ((rc = dalloc(st.status, Bz))) return rc;
     if ((rc = dalloc(st.qp_iter, Bz))) return rc;
+    if ((rc = dalloc(st.qp_work, Bz))) return rc;
     if ((rc = dalloc(st.finished, Bz))) return rc;
     if ((rc = dalloc(d_tlen, Bz))) return rc;
     if ((rc = dalloc(d_xin, Bz * 13))) return rc;
@@ -570,7 +571,7 @@ struct EngineT : mpcq_engine {
   }
   int get_cost(double* out) override { return d2h(out, st.cost, B); }
   int get_int(int which, int32_t* out) override {
-    const int* src = which == 0 ? st.status : (which == 1 ? st.qp_iter : (which == 2 ? st.idx : st.has_prev));
+    const int* src = which == 0 ? st.status : (which == 1 ? st.qp_iter : (which == 2 ? st.idx : (which == 4 ? st.qp_work : st.has_prev)));
     HIP_TRY(hipMemcpyAsync(out, src, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
@@ -892,6 +893,7 @@ int mpcq_get_u(mpcq_engine* e, int32_t s, double* o) { ENTER(e); return e->get_u
 int mpcq_get_cost(mpcq_engine* e, double* o) { ENTER(e); return e->get_cost(o); }
 int mpcq_get_status(mpcq_engine* e, int32_t* o) { ENTER(e); return e->get_int(0, o); }
 int mpcq_get_qp_iter(mpcq_engine* e, int32_t* o) { ENTER(e); return e->get_int(1, o); }
+int mpcq_get_qp_work(mpcq_engine* e, int32_t* o) { ENTER(e); if (!o) return fail(MPCQ_ERR_INVALID, "null argument"); return e->get_int(4, o); }
 int mpcq_get_stats(mpcq_engine* e, double* t) {
   ENTER(e);
   if (e->timed) {

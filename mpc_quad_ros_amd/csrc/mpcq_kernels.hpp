@@ -247,6 +247,7 @@ struct DevState {
   const int* tlen;
   int* status;
   int* qp_iter;
+  int* qp_work;     // [B] what the last solve executed: factorisations | vector sweeps << 16 (mpcq_get_qp_work)
   int* finished;    // [B] trajectory finished (src/mpc_controller_node.py:374), sticky until new trajectories / reset
   TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
   double* run_x;    // [B][13] plant states of the free-running closed loop (MODE_RUN; aliases x_meas)
@@ -1889,7 +1890,7 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const Lds& L, int* status, const int prev_iter PF_ARG) {
+MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const Lds& L, int* status, const int prev_iter, int* work PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0, why = 0;
   TQ gm = 1;
@@ -1911,6 +1912,7 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const 
     if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap, why PF_PASS)
                         : polish_incremental<C>(m, S, A, Kb, L, gm, wpasses, true, warm_cap, why PF_PASS)) {   // sets z = 0 and its own gradient scale
       *status = 0;
+      *work = wpasses | (wpasses << 16);   // one (possibly resumed) factorisation and one forward sweep per pass
       return wpasses;
     }
     wpasses += 1000;
@@ -1959,6 +1961,11 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const 
       chg += was != is ? 1 : 0;
     }
     chg = wave_sum(chg);
+  }
+  {   // factorisations: warm passes + interior-point iterations + passes behind it; sweeps: one per pass, two forward + one backward
+      // (+ the adjoint in fp32) per interior-point iteration, rollout + adjoint of the interior start, the final rollout
+    const int wp = wpasses % 1000;
+    *work = (it + passes + wp) | ((wp + passes + (sizeof(TQ) == 4 ? 4 : 3) * it + 2 + (need_roll ? 1 : 0)) << 16);
   }
   return it + passes + wpasses + (m.flip_max >= 0 && chg > m.flip_max ? 10000 : 0) + 100000 * why;
 }
@@ -2212,7 +2219,8 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   // ---- 2. QP
   int status = 0;
   const int prev_iter = st.qp_iter[b];
-  const int iters = solve_qp<C>(m, S, A, G, L, &status, prev_iter PF_PASS);
+  int work = 0;
+  const int iters = solve_qp<C>(m, S, A, G, L, &status, prev_iter, &work PF_PASS);
 #ifdef MPCQ_TRACE_NAN
   trace(2, nonfinite(S, L.z, nv) | nonfinite(S, L.dx, (N + 1) * VS) << 1 | (unsigned long long)(status & 0xff) << 8 | (unsigned long long)(unsigned)iters << 32);
 #endif
@@ -2271,7 +2279,7 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   // TQ = float: a step whose QP went through the interior-point fallback is outside the 1e-4 control budget of the fast mode
   // (include/mpcq.h, MPCQ_SOLVE_LOW_ACCURACY): taken, but reported
   if (sizeof(TQ) == 4 && status == 0 && ((iters / 1000) % 10 != 0 || prev_iter == 0)) status = 8;   // fallback solve or cold start
-  if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; }
+  if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; st.qp_work[b] = work; }
 #ifdef MPCQ_TRACE_NAN
   trace(3, (unsigned long long)(status & 0xff) | (unsigned long long)unsound << 8 | (unsigned long long)bad << 9 | (unsigned long long)(unsigned)prev_iter << 32);
 #endif

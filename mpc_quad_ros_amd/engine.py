@@ -144,6 +144,12 @@ class Engine:
         self._check(self.lib.mpcq_get_qp_iter(self.h, _lib.i(out)))
         return out
 
+    def get_qp_work(self):
+        """(factorisations, vector sweeps) the last solve of every quadrotor executed."""
+        out = np.zeros(self.B, np.int32)
+        self._check(self.lib.mpcq_get_qp_work(self.h, _lib.i(out)))
+        return out & 0xFFFF, out >> 16
+
     def get_block_order(self):
         """Launch order of the last lockstep period: workgroup p ran quadrotor out[p] (identity when unused)."""
         out = np.zeros(self.B, np.int32)

@@ -68,6 +68,10 @@ def case_teacher_forced_log(make_engine, name, K, precision=0, check_rgp=True):
         assert np.array_equal(se["idx"], so["idx"]) and np.array_equal(se["has_prev"], so["has_prev"])
     if outliers:
         print(f"{name}: f32 steps flagged MPCQ_SOLVE_LOW_ACCURACY (step, relative control deviation): {outliers}")
+    # flagged steps may be many (teacher-forced, the fallback mark of the engine persists), flagged steps OUTSIDE the 1e-4 budget stay the
+    # exception on the reference logs (round-2 report profiles/r2_f32_log_report.json: at most 5 per log)
+    over = [(k, err) for k, err in outliers if err >= TOL_TF[1]]
+    assert len(over) <= max(6, K // 12), (name, over)
     return worst
 
 

@@ -3,11 +3,11 @@
 # trace summary and the PMC passes (each in its own run, kernel-trace only) the numbers in profiles/ come from.  Every
 # pass runs THE SAME bench command (same pre-roll, warm-up and steps), so kernel time, counters and traffic describe
 # the same launches; the program itself follows `--` (no env / bash -c hop under the profiler).
-TAG=${1:-r3_final}; shift
+TAG=${1:-r4_final_k20}; shift
 O=gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-ARGS="--no-cpu-baseline --no-alt --no-configs --no-parity $@"   # the profiled program: headline leg only (same pre-roll, warm-up, steps)
+ARGS="--no-cpu-baseline --no-alt --no-configs --no-parity --steady 0 $@"   # the profiled program: headline leg only (same pre-roll, warm-up, steps; no steady-state / latency legs)
 echo "$@" > $O/args_$TAG.txt
 python3 bench.py $@ > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -- python3 bench.py $ARGS > $O/prof_$TAG.log 2>&1

@@ -53,20 +53,20 @@ template <int WHAT> __global__ __launch_bounds__(64) void kern(DevModel<double> 
   double* G = stage + (size_t)blockIdx.x * L.gtotal;
   int acc = 0;
   for (int r = 0; r < reps; ++r) {
-    if (WHAT == 0) acc += riccati_factor<C, false>(m, S, G, L) ? 1 : 0;
-    if (WHAT == 1) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, L, &g, G + L.mrow, G + L.pst, -1) ? 1 : 0; }
-    if (WHAT == 2) riccati_forward<C>(m, S, G, L, L.dz);
-    if (WHAT == 3) riccati_backward_vec<C>(m, S, G, L, false);
-    if (WHAT == 4) riccati_forward<C, true>(m, S, G, L, L.dz);
-    if (WHAT == 5) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, L, &g, G + L.mrow, (double*)nullptr, -1) ? 1 : 0; }
-    if (WHAT == 6) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, L, &g, (double*)nullptr, (double*)nullptr, -1) ? 1 : 0; }
+    if (WHAT == 0) acc += riccati_factor<C, false>(m, S, G, S, L) ? 1 : 0;
+    if (WHAT == 1) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, S, L, &g, G + L.mrow, G + L.pst, -1) ? 1 : 0; }
+    if (WHAT == 2) riccati_forward<C>(m, S, G, S, L, L.dz);
+    if (WHAT == 3) riccati_backward_vec<C>(m, S, G, S, L, false);
+    if (WHAT == 4) riccati_forward<C, true>(m, S, G, S, L, L.dz);
+    if (WHAT == 5) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, S, L, &g, G + L.mrow, (double*)nullptr, -1) ? 1 : 0; }
+    if (WHAT == 6) { double g = 0; acc += riccati_factor<C, true, true>(m, S, G, S, L, &g, (double*)nullptr, (double*)nullptr, -1) ? 1 : 0; }
     if (WHAT == 8) mock_forward<true>(m, S, G, L, L.dz);
     if (WHAT == 9) mock_forward<false>(m, S, G, L, L.dz);
     if (WHAT == 10) mock_forward<false, 6>(m, S, G, L, L.dz);
     if (WHAT == 11) mock_forward<false, 2, 1>(m, S, G, L, L.dz);
     if (WHAT == 12) mock_forward<false, 2, 2>(m, S, G, L, L.dz);
     if (WHAT == 13) mock_forward<false, 2, 0>(m, S, S, L, L.dz);
-    if (WHAT == 7) acc += riccati_factor<C, true>(m, S, G, L) ? 1 : 0;
+    if (WHAT == 7) acc += riccati_factor<C, true>(m, S, G, S, L) ? 1 : 0;
   }
   if (acc == 12345) sink[blockIdx.x] = acc;
 }

@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
 from mpc_quad_ros_amd.trajectories import swarm_trajectories
 
+os.environ["MPCQ_TUNING"] = "1"     # the library reads MPCQ_STAGE_MEM / MPCQ_GENERIC only under MPCQ_TUNING=1 (since 0.3): without it the four variants below would be one
 lib = ctypes.CDLL(os.path.abspath(sys.argv[1]))
 dp = ctypes.POINTER(ctypes.c_double)
 ip = ctypes.POINTER(ctypes.c_int32)

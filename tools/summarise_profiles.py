@@ -18,8 +18,8 @@ P = os.path.join(ROOT, "profiles")
 
 
 def is_lockstep(name):
-    """step_kernel<Cfg<T, GAB, N, NB, RUN>, ...>: RUN = false is the one-launch-per-period instance."""
-    m = re.search(r"step_kernel<mpcq::Cfg<\w+, (?:true|false), -?\d+, -?\d+, (true|false)>", name)
+    """step_kernel<Cfg<T, GAB, N, NB, RUN, GK>, ...>: RUN = false is the one-launch-per-period instance."""
+    m = re.search(r"step_kernel<mpcq::Cfg<\w+, (?:true|false), -?\d+, -?\d+, (true|false)(?:, (?:true|false))?>", name)
     return bool(m) and m.group(1) == "false"
 
 
@@ -55,7 +55,7 @@ for grp in ("fetch", "write", "sq", "mfma", "mem"):
     for k in acc:
         pmc[k] = acc[k] / cnt[k]
         pmc["launches_" + grp] = cnt[k]
-pmc["note"] = "per-launch means over the lockstep step_kernel launches (warm-up + timed steps) of the SAME command as the bench line and the kernel trace (`bench.py --no-cpu-baseline --no-alt --no-configs --no-parity` + the tag's arguments); one rocprofv3 --pmc pass per group"
+pmc["note"] = "per-launch means over the lockstep step_kernel launches (warm-up + timed steps) of the SAME command as the bench line and the kernel trace (`bench.py --no-cpu-baseline --no-alt --no-configs --no-parity --steady 0` + the tag's arguments); one rocprofv3 --pmc pass per group"
 with open(os.path.join(P, f"{TAG}_pmc.json"), "w") as f:
     json.dump(pmc, f, indent=1)
 prec = bench["dtype"]
@@ -74,7 +74,7 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     t["source_sha16"] = _bench.kernel_source_sha16()
     t["args"] = {"steps": bench["steps"], "warmup": bench["warmup"], "preroll": cfg["preroll_periods"], "seed": int(os.environ.get("BENCH_SEED", "2026")),
                  "batch": cfg["batch_per_gpu"], "N": cfg["horizon_nodes"], "nb": cfg["rgp_basis"], "precision": prec}
-    t["command"] = "python3 bench.py --no-cpu-baseline --no-alt --no-configs --no-parity " + open(os.path.join(O, f"args_{TAG}.txt")).read().strip()
+    t["command"] = "python3 bench.py --no-cpu-baseline --no-alt --no-configs --no-parity --steady 0 " + open(os.path.join(O, f"args_{TAG}.txt")).read().strip()
     try:
         import subprocess
         t["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip() + " (+ working tree at collection time)"
