@@ -417,11 +417,13 @@ struct EngineT : mpcq_engine {
       }
     }
     int layout = (occ[0] == 0 || (occ[1] > occ[0] && (size_t)B > occ[0] * n_cu)) ? 1 : 0;
-    // (the compact instance is a few per cent slower per wave -- 256 registers, gains through L2 --, so it has to save a whole
-    //  round of workgroups to pay: measured at B = 2 048, N = 20: two rounds either way, 5.03 M steps/s against 4.83 M compact)
+    // (the compact instance is a few per cent slower per wave -- 256 registers, gains through L2 -- and adds memory-side traffic, so it
+    //  takes a long stream of workgroups to pay.  Measured at N = 20, nb = 10, M steps/s layout 1 / compact: B = 2 048 5.03 / 4.83, 3 072
+    //  7.04 / 6.68, 4 096 8.61 / 8.22, 6 144 9.91 / 10.49, 8 192 10.5 / 11.7, 16 384 9.5 / 10.6: from five rounds of layout 1 on.
+    //  N = 50, nb = 50 (one against two per CU): B = 4 096 0.70 / 1.22.)
     {
-      const size_t r1 = occ[layout] * n_cu, r2 = occ[2] * n_cu;
-      if (occ[2] > occ[layout] && ((size_t)B + r2 - 1) / r2 < ((size_t)B + r1 - 1) / r1) layout = 2;
+      const size_t r1 = occ[layout] * n_cu;
+      if (occ[2] > occ[layout] && (size_t)B >= 5 * r1) layout = 2;
     }
     if (tu.stage_mem) layout = tu.stage_mem - 1;
     if (const char* t = env ? getenv("MPCQ_STAGE_MEM") : nullptr) layout = (t[0] == 'c' || t[0] == 'C') ? 2 : ((t[0] == 'g' || t[0] == 'G') ? 1 : 0);

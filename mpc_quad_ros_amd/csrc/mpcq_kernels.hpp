@@ -1418,6 +1418,9 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const L
     rdm = wave_max(rdm);
     mu = wave_sum(mu) / (2 * nv);
     if (!(rdm == rdm) || !(mu == mu)) { status = 1; break; }
+#ifdef MPCQ_EMU_DEBUG
+    if (tid == 0) printf("  ipm it %2d: |r_d|/gm %.3e  mu %.3e  (tol %.1e)\n", it, (double)(rdm / gm), (double)mu, (double)tol);
+#endif
     if (rdm <= tol * gm && mu <= tol) { status = 0; break; }
     // predictor: (H + Sigma) dza = -grad
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
@@ -1479,6 +1482,9 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const L
     const TQ tau = tmax(TQ(0.995), 1 - mu);
     // alpha = min(1, tau / max_i(...)): the maxima start at 1, i.e. an unrestricted step has length tau
     TQ ap = tmin(TQ(1), tau * trcp(wave_max(apinv))), ad = tmin(TQ(1), tau * trcp(wave_max(adinv)));
+#ifdef MPCQ_EMU_DEBUG
+    if (tid == 0) printf("             affine step %.3f  sigma %.2e  alpha_p %.4f  alpha_d %.4f\n", (double)aff, (double)sigma, (double)ap, (double)ad);
+#endif
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
       const TQ dl = S[L.act + i], du = S[L.rt + i];

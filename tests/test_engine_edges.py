@@ -72,6 +72,26 @@ def _reset_and_state_roundtrip(lib):
         assert np.array_equal(s[k], s2[k]), k
 
 
+def _work_counters(lib):
+    """mpcq_get_qp_work: factorisations | sweeps << 16 of every quadrotor's last solve, consistent with the decimal fields of qp_iter:
+    a cold start goes through the interior point (several factorisations, three sweeps per iteration + the start's two + passes), a warm
+    success is one factorisation and one forward sweep per pass."""
+    from mpc_quad_ros_amd.engine import qp_fallback, qp_passes
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B = 6
+    e = Engine(EngineConfig(batch=B, N=10, quad=hummingbird(), nb=10, basis=rgp_basis_linspace(12.0, 10)), lib_path=lib)
+    traj, lens = swarm_trajectories(4, 0, B)
+    e.set_trajectories(traj, lens); e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
+    e.sim_steps(1, 2, 5e-3)
+    it, (fac, swp) = e.get_qp_iter(), e.get_qp_work()
+    assert np.array_equal(fac, qp_passes(it)) and (fac >= 3).all() and (swp >= 3 * (fac - 2)).all()      # cold start: interior point
+    e.sim_steps(3, 2, 5e-3)
+    it, (fac, swp) = e.get_qp_iter(), e.get_qp_work()
+    warm = ~qp_fallback(it)
+    assert warm.any() and np.array_equal(fac[warm], qp_passes(it)[warm]) and np.array_equal(swp[warm], fac[warm])
+    e.close()
+
+
 def _argument_errors(lib):
     with pytest.raises(_lib.MpcqError):
         Engine(EngineConfig(batch=0, N=5), lib_path=lib)
@@ -371,7 +391,7 @@ def _static_gp_model_path(lib):
 
 CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log, _free_running_equals_lockstep,
          _command_and_finished, _chunk_cases_on_device, _plant_period_matches_reference_logs, _checkpoint_resume_is_bitwise,
-         _rgp_learn_matches_reference_streams, _static_gp_model_path]
+         _rgp_learn_matches_reference_streams, _static_gp_model_path, _work_counters]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.__name__.strip("_") for c in CASES])
