@@ -34,12 +34,12 @@ template <typename T> using StepFn = void (*)(const DevModel<T>, const DevState<
 #define MPCQ_DECL(n, nb) MPCQ_DECL_(n, nb)
 MPCQ_SPEC_SHAPES(MPCQ_DECL)
 #undef MPCQ_DECL
-// specialised free-running fp64 instances: the shapes of MPCQ_SPEC_RUN_SHAPES (Makefile: SPEC_RUN_SHAPES; reproducer builds: every shape)
+// specialised free-running instances: the shapes of MPCQ_SPEC_RUN_SHAPES (Makefile: SPEC_RUN_SHAPES; reproducer builds: every shape)
 #if defined(MPCQ_SPEC_RUN) && !defined(MPCQ_SPEC_RUN_SHAPES)
 #define MPCQ_SPEC_RUN_SHAPES(X) MPCQ_SPEC_SHAPES(X)
 #endif
 #ifdef MPCQ_SPEC_RUN_SHAPES
-#define MPCQ_DECLR_(n, nb) StepFn<double> spec_run_f64_##n##_##nb(int layout);
+#define MPCQ_DECLR_(n, nb) StepFn<double> spec_run_f64_##n##_##nb(int layout); StepFn<float> spec_run_f32_##n##_##nb(int layout);
 #define MPCQ_DECLR(n, nb) MPCQ_DECLR_(n, nb)
 MPCQ_SPEC_RUN_SHAPES(MPCQ_DECLR)
 #endif
@@ -60,7 +60,9 @@ static mpcq::StepFn<float> spec_step(int N, int nb, int layout, float*) {
 #define MPCQ_TRYR_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_run_f64_##n##_##nb_(layout);
 #define MPCQ_TRYR(n, nb_) MPCQ_TRYR_(n, nb_)
 static mpcq::StepFn<double> spec_run(int N, int nb, int layout, double*) { MPCQ_SPEC_RUN_SHAPES(MPCQ_TRYR) return nullptr; }
-static mpcq::StepFn<float> spec_run(int, int, int, float*) { return nullptr; }
+#define MPCQ_TRYR32_(n, nb_) if (N == n && nb == nb_) return mpcq::spec_run_f32_##n##_##nb_(layout);
+#define MPCQ_TRYR32(n, nb_) MPCQ_TRYR32_(n, nb_)
+static mpcq::StepFn<float> spec_run(int N, int nb, int layout, float*) { MPCQ_SPEC_RUN_SHAPES(MPCQ_TRYR32) return nullptr; }
 #endif
 
 namespace {

@@ -16,7 +16,7 @@
 #define MPCQ_SPEC_NAME(prefix, n, nb) MPCQ_CAT3(prefix, n, nb)
 
 // Two kinds of objects per shape (Makefile): spec_N_NB.o = the LOCKSTEP instances (one launch per control period), specrun_N_NB.o
-// (-DMPCQ_SPEC_RUN_ONLY) = the FREE-RUNNING fp64 instances (mpcq_sim_run), for the shapes listed in SPEC_RUN_SHAPES.
+// (-DMPCQ_SPEC_RUN_ONLY) = the FREE-RUNNING instances (mpcq_sim_run), for the shapes listed in SPEC_RUN_SHAPES.
 // Round 3 withdrew the specialised free-running instances after wrong results and a device fault that depended on code
 // generation; round 4 found the cause (tools/repro_codegen/README.md): ROCm 7.2's register allocator can put VGPR -> AGPR spill
 // copies IN FRONT of the EXEC restore of a control-flow join (behind SGPR spills it placed there first), where they execute for
@@ -47,11 +47,13 @@ StepFn<float> MPCQ_SPEC_NAME(spec_lock_f32_, MPCQ_SPEC_N, MPCQ_SPEC_NB)(int layo
 
 #endif   // !MPCQ_SPEC_RUN_ONLY
 
-#if defined(MPCQ_SPEC_RUN) || defined(MPCQ_SPEC_RUN_ONLY)   // shape-specialised FREE-RUNNING fp64 instances (see the note at the top)
-StepFn<double> MPCQ_SPEC_NAME(spec_run_f64_, MPCQ_SPEC_N, MPCQ_SPEC_NB)(int layout) {
-  if (layout == 2) return &step_kernel<Cfg<double, true, MPCQ_SPEC_N, MPCQ_SPEC_NB, true, true>>;
-  return layout == 1 ? &step_kernel<Cfg<double, true, MPCQ_SPEC_N, MPCQ_SPEC_NB, true>> : &step_kernel<Cfg<double, false, MPCQ_SPEC_N, MPCQ_SPEC_NB, true>>;
+#if defined(MPCQ_SPEC_RUN) || defined(MPCQ_SPEC_RUN_ONLY)   // shape-specialised FREE-RUNNING instances (see the note at the top)
+template <typename T> static StepFn<T> pick_run(int layout) {
+  if (layout == 2) return &step_kernel<Cfg<T, true, MPCQ_SPEC_N, MPCQ_SPEC_NB, true, true>>;
+  return layout == 1 ? &step_kernel<Cfg<T, true, MPCQ_SPEC_N, MPCQ_SPEC_NB, true>> : &step_kernel<Cfg<T, false, MPCQ_SPEC_N, MPCQ_SPEC_NB, true>>;
 }
+StepFn<double> MPCQ_SPEC_NAME(spec_run_f64_, MPCQ_SPEC_N, MPCQ_SPEC_NB)(int layout) { return pick_run<double>(layout); }
+StepFn<float> MPCQ_SPEC_NAME(spec_run_f32_, MPCQ_SPEC_N, MPCQ_SPEC_NB)(int layout) { return pick_run<float>(layout); }
 #endif
 
 }  // namespace mpcq
