@@ -47,7 +47,7 @@ def test_emu_swarm_closed_loop_hummingbird():
 
 
 def test_emu_saturating_references_many_working_sets():
-    worst, hist, failed = pc.case_saturating_references(make, B=2, K=22)
+    worst, hist, failed = pc.case_saturating_references(make, B=2, K=17)
     assert failed == 0
     print("saturating references: worst", worst, "passes", dict(sorted(hist.items())))
     assert worst < 1e-7
@@ -61,7 +61,7 @@ def test_emu_saturating_references_long_warm_attempts():
     releases over several factorisations) end on the same optimum."""
     tune = dict(abort_pins=-1, abort_wrong=-1, flip_max=-1, warm_max=14, warm_retry=14)
     make_t = lambda cfg: make(dataclasses.replace(cfg, tune=tune))
-    worst, hist, failed = pc.case_saturating_references(make_t, B=2, K=14)
+    worst, hist, failed = pc.case_saturating_references(make_t, B=2, K=11)
     print("saturating references, long warm attempts: worst", worst, "passes", dict(sorted(hist.items())))
     assert failed == 0 and worst < 1e-7
     assert sum(n for v, n in hist.items() if 3 <= v % 1000 <= 14 and v < 1000) >= 4
@@ -112,8 +112,8 @@ def test_emu_compact_layout_against_oracle():
     the stage records; r0 / lb / ub written behind the shooting into the space of its records): warm active-set solves,
     interior-point fallbacks and flip-marked quadrotors against the oracle."""
     make_c = lambda cfg: make(dataclasses.replace(cfg, tune=dict(stage_mem="compact")))
-    assert pc.case_teacher_forced_log(make_c, "log_trajectory_v15_a5_gp2.npz", 8) < 1e-8
-    worst, hist, failed = pc.case_saturating_references(make_c, B=2, K=10)
+    assert pc.case_teacher_forced_log(make_c, "log_trajectory_v15_a5_gp2.npz", 5) < 1e-8
+    worst, hist, failed = pc.case_saturating_references(make_c, B=2, K=8)
     assert failed == 0 and worst < 1e-7
     from mpc_quad_ros_amd.engine import qp_fallback
     assert any(qp_fallback(v) for v in hist)
