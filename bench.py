@@ -209,7 +209,7 @@ def lockstep_leg(e, n_sub, warmup, steps, dist=None):
     e.sim_steps(steps, n_sub, 5e-3)          # K fused steps + plant, back-to-back on one stream
     t_own = barrier()
     t1 = time.perf_counter()
-    kt, kl = e.get_kernel_time()             # HIP events around the step-kernel launches (all of them when steps <= 50, else every 4th)
+    kt, kl = e.get_kernel_time()             # HIP events around every 4th step-kernel launch (every launch when steps < 8)
     return t1 - t0, t_own - t0, kt / max(kl, 1)
 
 
@@ -502,7 +502,7 @@ def main():
     start = None
     if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_parity):   # where the CPU legs continue from
         start = dump_engine(e)
-    ktime, klaunch = e.get_kernel_time()     # HIP events around the step_kernel launches of the timed region (all of them when steps <= 50, else every 4th)
+    ktime, klaunch = e.get_kernel_time()     # HIP events around the step_kernel launches of the timed region (every 4th; every launch when steps < 8)
     kmin, kmax = e.get_kernel_time_minmax()
     its = e.get_qp_iter()
     status = e.get_status()
@@ -590,7 +590,7 @@ def main():
                          "kernel_avg_ms": 1e3 * k_avg, "kernel_min_ms": 1e3 * kmin, "kernel_max_ms": 1e3 * kmax,
                          "kernel_launches": args.steps, "kernel_launches_timed": klaunch,
                          "timing": "HIP events on the engine's stream around the step-kernel launches of the timed region "
-                                   "(every launch when steps <= 50, else every 4th; MPCQ_KEV_STRIDE)",
+                                   "(every 4th launch; every launch when steps < 8: an event pair between dependent launches costs dispatch overlap, 2.4 % at 20 launches)",
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "path is latency/VALU/LDS bound, not HBM bound (DESIGN.md): secondary figure below",
                          "vector_flops": {"achieved_tflops": flops_launch / k_avg / 1e12,

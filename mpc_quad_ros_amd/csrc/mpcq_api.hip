@@ -639,9 +639,10 @@ struct EngineT : mpcq_engine {
     if (!have_traj) return fail(MPCQ_ERR_STATE, "mpcq_sim_steps needs mpcq_set_trajectories first");
     mpcq::DevState<T> s2 = st;
     s2.x_meas = d_xs;
-    // HIP events around every `stride`-th step-kernel launch (an event pair costs a few microseconds of dispatch
-    // overlap, so only a sample of the launches carries one; MPCQ_KEV_STRIDE=1 times every launch)
-    int stride = K <= 50 ? 1 : 4;   // short runs: every launch
+    // HIP events around every 4th step-kernel launch: an event pair between two dependent launches costs dispatch overlap (measured
+    // at B = 1 024, 20 launches: pairs on every launch 3.18 M steps/s, on every 2nd 3.22, every 4th 3.25, none 3.26), so only a sample of
+    // the launches carries one (calls of fewer than 8 periods: every launch; MPCQ_KEV_STRIDE under MPCQ_TUNING=1 overrides)
+    int stride = K < 8 ? 1 : 4;
     if (const char* t = tuning_env ? getenv("MPCQ_KEV_STRIDE") : nullptr) stride = atoi(t) > 0 ? atoi(t) : 1;
     const int nev = (K + stride - 1) / stride;
     while ((int)kev.size() < 2 * nev) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
