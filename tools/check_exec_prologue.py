@@ -10,7 +10,8 @@
 
 The check disassembles every kernel and reports, per basic block, EXEC-dependent vector instructions that sit between the
 start of the block and a leading  s_or_b64 exec, exec, ...  (no other EXEC write in between).  v_writelane / v_readlane /
-v_readfirstlane and scalar instructions ignore EXEC and are fine there.
+v_readfirstlane and scalar instructions ignore EXEC and are fine there; an SGPR spill to scratch (-amdgpu-spill-sgpr-to-vgpr=0) that saves
+EXEC, sets it to a constant and restores it is looked through.
 
 usage: check_exec_prologue.py file.o|file.so|file.s [...]      exit status 1 if any kernel shows the pattern"""
 import re
@@ -136,11 +137,23 @@ def check(ins):
         prev = next((ins[k][1] for k in range(i - 1, -1, -1) if ins[k][0] is None), "")
         exec_zero = prev.startswith("s_cbranch_execnz")
         head = []
+        saved, inside = None, False      # SGPR spills to scratch wrap themselves in  s_mov sX, exec / s_mov exec, imm / ... / s_mov exec, sX: EXEC is unchanged behind them
         for j in range(i + 1, n):
             if ins[j][0] is not None:
                 break
             t = ins[j][1]
             op = t.split()[0]
+            m = re.match(r"s_mov_b64 (s\[\d+:\d+\]), exec$", t)
+            if m and not inside:
+                saved = m.group(1)
+                continue
+            if saved and not inside and re.match(r"s_mov_b64 exec, (-?\d+|0x[0-9a-f]+)$", t):
+                inside = True
+                continue
+            if inside:
+                if t == f"s_mov_b64 exec, {saved}":
+                    inside, saved = False, None
+                continue
             if re.match(r"s_or_b64 exec, exec,", t):
                 dep = [h for h in head if not h.startswith(IGNORES_EXEC)]
                 bad = dep if exec_zero else [h for h in dep if h.startswith(SPILL_OPS)]
