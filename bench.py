@@ -546,6 +546,22 @@ def main():
         es.close()
         best = sranks["steps_per_s"]["max"]
         swarm_out = dict(leg)
+        # HBM roofline of this leg (per GPU): algorithmic bytes over the launch time by HIP events; memory-side traffic from the rocprofv3 passes of this
+        # configuration, attached only when they were taken on this build (source hash)
+        sw_bytes = algorithmic_bytes(20, 10, 8) * SWARM_PER_RANK
+        sw_roof = {"bound": "hbm", "achieved": sw_bytes / (leg["kernel_avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                   "algorithmic_bytes_per_launch": sw_bytes}
+        sw_roof["frac"] = sw_roof["achieved"] / HBM_PEAK_GBS
+        try:
+            with open(os.path.join(ROOT, "profiles", "r4_pmc_traffic_swarm_b8192.json")) as fh:
+                tsw = json.load(fh)
+            if tsw.get("source_sha16") == kernel_source_sha16():
+                sw_roof["traffic"] = tsw["hbm_bytes_per_launch"]
+                sw_roof["traffic_frac_of_peak"] = tsw["hbm_bytes_per_launch"] / (leg["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                sw_roof["traffic_source"] = "profiles/r4_pmc_traffic_swarm_b8192.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/large_batch.py 8192 20 10, same build)"
+        except (OSError, ValueError):
+            pass
+        swarm_out["roofline"] = sw_roof
         swarm_out.update({"config": f"BASELINE configs[3]: swarm of {SWARM_PER_RANK * world} quadrotors, {SWARM_PER_RANK} per GPU over {world} GPU(s)"
                                     + (" (= the per-rank shard of the 65 536-quadrotor swarm)" if world == 1 else ""),
                           "value": SWARM_PER_RANK * world * SWARM_STEPS / agg_dt, "n_gpus": world, "global_batch": SWARM_PER_RANK * world,
@@ -672,7 +688,7 @@ def main():
             # the other BASELINE configurations, reachable from the driver's command: short lockstep legs after the headline
             out["configs"] = [
                 config_leg("configs[2]: batch 8192, N=20, RGP 20 basis pts", refs_cfg, 8192, 20, 20, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
-                {k: v for k, v in swarm_out.items() if k not in ("per_rank", "efficiency_vs_best_rank", "n_gpus", "global_batch", "stats_reduce", "tracking_steps")}
+                {k: v for k, v in swarm_out.items() if k not in ("per_rank", "efficiency_vs_best_rank", "n_gpus", "global_batch", "stats_reduce", "tracking_steps", "roofline")}
                 | {"config": f"configs[3] per rank: batch {SWARM_PER_RANK} of {SWARM_PER_RANK * 8}, N=20, RGP 10 basis pts (the `swarm` leg of this line: same pre-roll as an N > 1 run)"},
                 config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
                 config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F32, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
