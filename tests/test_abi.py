@@ -60,6 +60,21 @@ def test_code_objects_pass_the_exec_prologue_check():
         pytest.skip("no ROCm LLVM tools on this runner")
     bad = subprocess.run([sys.executable, chk, os.path.join(ROOT, "tools", "repro_codegen", "isa_excerpt_BB10_117.s")], capture_output=True, text=True)
     assert bad.returncode == 1 and "EXEC = 0" in bad.stdout and "v_accvgpr_write_b32" in bad.stdout, bad.stdout
+    # the same misplacement behind an SGPR spill to scratch (-amdgpu-spill-sgpr-to-vgpr=0: EXEC saved, set to a constant, restored) and a
+    # legitimate join (per-lane copy at the end of a divergent `if`, nothing but the EXEC restore behind a loop exit)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        bad2, ok2 = os.path.join(tmp, "bad.s"), os.path.join(tmp, "ok.s")
+        open(bad2, "w").write("_ZN4mpcq11step_kernel_synthetic_badEv:\n.LBB0_1:\n\ts_andn2_b64 exec, exec, s[18:19]\n\ts_cbranch_execnz .LBB0_1\n.LBB0_2:\n"
+                              "\ts_mov_b64 s[4:5], exec\n\ts_mov_b64 exec, 3\n\tscratch_store_dword off, v0, off offset:8\n\tv_writelane_b32 v0, s34, 0\n"
+                              "\ts_mov_b64 exec, s[4:5]\n\tv_accvgpr_write_b32 a1, v7\n\ts_or_b64 exec, exec, s[2:3]\n\ts_endpgm\n.Lfunc_end0:\n")
+        open(ok2, "w").write("_ZN4mpcq11step_kernel_synthetic_okEv:\n.LBB1_1:\n\ts_andn2_b64 exec, exec, s[18:19]\n\ts_cbranch_execnz .LBB1_1\n.LBB1_2:\n"
+                             "\tv_writelane_b32 v9, s34, 0\n\ts_or_b64 exec, exec, s[2:3]\n\tv_accvgpr_write_b32 a1, v7\n\ts_cbranch_execz .LBB1_4\n.LBB1_3:\n\tv_mov_b32_e32 v3, v4\n.LBB1_4:\n"
+                             "\tv_mov_b32_e32 v5, v3\n\ts_or_b64 exec, exec, s[6:7]\n\ts_endpgm\n.Lfunc_end1:\n")
+        r_bad = subprocess.run([sys.executable, chk, bad2], capture_output=True, text=True)
+        r_ok = subprocess.run([sys.executable, chk, ok2], capture_output=True, text=True)
+        assert r_bad.returncode == 1 and "v_accvgpr_write_b32 a1, v7" in r_bad.stdout, r_bad.stdout
+        assert r_ok.returncode == 0, r_ok.stdout
     good = subprocess.run([sys.executable, chk, _lib.DEFAULT_LIB], capture_output=True, text=True)
     assert good.returncode == 0, good.stdout[-2000:]
     assert good.stdout.count("clean") >= 20          # every step-kernel instance of the library was looked at
