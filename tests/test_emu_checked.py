@@ -29,6 +29,10 @@ out["saturating"] = dict(worst=worst, failed=failed, fallbacks=sum(n for v, n in
 out["swarm"] = pc.case_swarm_closed_loop(make, B=2, N=10, nb=10, K=5)
 out["swarm_f32"] = pc.case_swarm_closed_loop(make, B=2, N=10, nb=10, K=4, precision=1)
 pc.case_explicit_api(make, B=2, N=5, nb=10)
+import dataclasses
+make_c = lambda cfg: make(dataclasses.replace(cfg, tune=dict(stage_mem="compact")))   # gains in the global record, r0/lb/ub inside the union
+worst_c, hist_c, failed_c = pc.case_saturating_references(make_c, B=2, K=8)
+out["compact"] = dict(worst=worst_c, failed=failed_c, fallbacks=sum(n for v, n in hist_c.items() if v >= 1000), swarm=pc.case_swarm_closed_loop(make_c, B=2, N=10, nb=10, K=3))
 import test_engine_edges as te
 te._ragged_and_exhausted(%r)
 print(json.dumps(out))
@@ -59,6 +63,7 @@ def test_checked_build_clean_on_emulator(checked_lib, order):
     r = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert r["teacher_forced_active_bounds"] < 1e-8 and r["swarm"] < 1e-7 and r["saturating"]["worst"] < 1e-7
     assert r["saturating"]["failed"] == 0 and r["saturating"]["fallbacks"] > 0 and r["saturating"]["multi_pass"] > 0
+    assert r["compact"]["worst"] < 1e-7 and r["compact"]["failed"] == 0 and r["compact"]["fallbacks"] > 0 and r["compact"]["swarm"] < 1e-7
 
 
 def test_checked_build_reports_an_out_of_range_index(checked_lib):
