@@ -94,7 +94,7 @@ def kernel_source_sha16():
     box has no .git).  PMC traffic files carry it; a file from another build is not attached to this run's line."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("mpcq_kernels.hpp", "mpcq_api.hip", "mpcq_spec.hip", "Makefile"):
+    for f in ("mpcq_kernels.hpp", "mpcq_api.hip", "mpcq_spec.hip", "Makefile", "cc_checked.sh"):
         with open(os.path.join(ROOT, "mpc_quad_ros_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -619,6 +619,9 @@ def main():
         # THIS build (source hash) with THIS command line; otherwise null -- a number from another build is not this run's traffic.
         import glob
         sha = kernel_source_sha16()
+        from mpc_quad_ros_amd import _lib as _l
+        ver = _l.load().mpcq_version().decode()
+        out["library"] = {"version": ver, "built_from_these_sources": sha in ver}      # the Makefile puts the source hash into the version string
         key = {"steps": args.steps, "warmup": args.warmup, "preroll": args.preroll, "seed": args.seed, "batch": B, "N": N, "nb": nb,
                "precision": args.precision}
         out["roofline"]["traffic_note"] = f"no PMC profile of build {sha} for this command line under profiles/"

@@ -827,10 +827,13 @@ struct EngineT : mpcq_engine {
 extern "C" {
 
 const char* mpcq_last_error(void) { return g_err.c_str(); }
+#ifndef MPCQ_SRC_ID   // csrc/Makefile: the first 16 hex digits of sha256(mpcq_kernels.hpp | mpcq_api.hip | mpcq_spec.hip | Makefile | cc_checked.sh) = bench.kernel_source_sha16()
+#define MPCQ_SRC_ID "unknown"
+#endif
 #ifdef MPCQ_CHECKED
-const char* mpcq_version(void) { return "mpcq 0.4 (gfx950, CHECKED diagnostic build)"; }
+const char* mpcq_version(void) { return "mpcq 0.4 (gfx950, CHECKED diagnostic build, source " MPCQ_SRC_ID ")"; }
 #else
-const char* mpcq_version(void) { return "mpcq 0.4 (gfx950)"; }
+const char* mpcq_version(void) { return "mpcq 0.4 (gfx950, source " MPCQ_SRC_ID ")"; }
 #endif
 
 int mpcq_create(const mpcq_config* c, mpcq_engine** out) { return mpcq_create_sized(c, sizeof(mpcq_config), out); }

@@ -126,6 +126,7 @@ template <typename T> struct CkPtr {
   }
   template <typename I> __device__ T& operator[](I i) const { return ok((long)i) ? p[(long)i] : const_cast<T&>(static_cast<const V&>(sink)); }
   template <typename I> __device__ CkPtr operator+(I o) const { return CkPtr(p + (long)o, lo - (long)o, hi - (long)o, tag); }
+  __device__ T& c(long k) const { return (*this)[k]; }   // see OffPtr::c
 };
 template <typename T> using P = CkPtr<T>;
 template <typename T> __device__ inline P<T> mk(T* p, long n, int tag) { return P<T>(p, n, tag); }
@@ -140,12 +141,35 @@ template <typename T> __device__ inline void st4(const P<T>& b, long off, const 
 #define CK_EXEC_FULL(site) ck_exec(site)
 #else
 constexpr int CK_HDR = 0;
-template <typename T> using P = T*;
-template <typename T> __device__ inline T* mk(T* p, long, int) { return p; }
-template <typename T> __device__ inline V4<typename std::remove_const<T>::type> ld4(T* b, long off) {
-  return *reinterpret_cast<const V4<typename std::remove_const<T>::type>*>(b + off);
+// Product build: P<T> = base pointer + unsigned 32-bit BYTE offset, kept apart until the access.  The base of every region is
+// wave-uniform (the LDS workspace, the record of this workgroup's quadrotor), so an access to a global record becomes
+// `global_load/store v, v_offset, s[base:base+1]` -- one 32-bit add per address where plain pointer arithmetic on T* costs an index
+// add, a sign extension and a 64-bit shift-add (three vector instructions per load; a fifth of the forward sweep over global stage
+// records was address arithmetic).  Offsets wrap modulo 2^32: every region is far smaller than 4 GiB and no access lies in front of
+// its region's base (the checked build verifies both).
+template <typename T> struct OffPtr {
+  using V = typename std::remove_const<T>::type;
+  T* b; unsigned o;
+  __host__ __device__ OffPtr() : b(nullptr), o(0) {}
+  __host__ __device__ OffPtr(decltype(nullptr)) : b(nullptr), o(0) {}
+  __host__ __device__ OffPtr(T* p) : b(p), o(0) {}
+  __host__ __device__ OffPtr(T* p, unsigned o_) : b(p), o(o_) {}
+  template <typename U> __host__ __device__ OffPtr(const OffPtr<U>& x) : b(x.b), o(x.o) {}
+  __host__ __device__ explicit operator bool() const { return b != nullptr; }
+  template <typename I> __host__ __device__ T& operator[](I i) const {
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<V*>(b)) + (o + (unsigned)i * (unsigned)sizeof(T)));
+  }
+  template <typename I> __host__ __device__ OffPtr operator+(I i) const { return OffPtr(b, o + (unsigned)i * (unsigned)sizeof(T)); }
+  // element at a compile-time-constant distance k (after unrolling): added behind the zero extension, where it becomes the
+  // immediate offset field of the instruction -- (p + lane_part).c(k) for several k shares one address register
+  __host__ __device__ T& c(long k) const { return *reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<V*>(b)) + (size_t)o + k * (long)sizeof(T)); }
+};
+template <typename T> using P = OffPtr<T>;
+template <typename T> __device__ inline P<T> mk(T* p, long, int) { return P<T>(p); }
+template <typename T> __device__ inline V4<typename std::remove_const<T>::type> ld4(const P<T>& b, long off) {
+  return *reinterpret_cast<const V4<typename std::remove_const<T>::type>*>(&b[off]);
 }
-template <typename T> __device__ inline void st4(T* b, long off, const V4<T>& v) { *reinterpret_cast<V4<T>*>(b + off) = v; }
+template <typename T> __device__ inline void st4(const P<T>& b, long off, const V4<T>& v) { *reinterpret_cast<V4<T>*>(&b[off]) = v; }
 #define CK_EXEC_FULL(site)
 #endif
 constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
@@ -367,6 +391,16 @@ __device__ inline int lane_id() {
 #endif
   return t;
 }
+// A zero the compiler has to take for a per-lane value.  Added to the index of an LDS broadcast read it keeps everything computed from
+// the value on the vector ALU: a wave-uniform value that feeds a select is otherwise moved to SGPRs, at two v_readfirstlane and an
+// s_cselect pair per operand (and, scalar floating point not existing on gfx950, comes back through v_mov for every comparison).
+__device__ inline int lane_zero() {
+  int z = 0;
+#if defined(__AMDGCN__)
+  asm volatile("" : "+v"(z));
+#endif
+  return z;
+}
 // lane broadcast: `lane` must be wave-uniform (a constant after unrolling) -> v_readlane_b32 into an SGPR
 __device__ inline int bc(int v, int lane) { CK_EXEC_FULL(1); return __builtin_amdgcn_readlane(v, lane); }
 __device__ inline float bc(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
@@ -517,16 +551,27 @@ template <typename PT> __device__ inline void vl_store(PT base, int h, const flo
   st4(base, 4 * h, t);
 }
 template <typename PT> __device__ inline void vl_load(PT base, int h, double (&v)[4]) {
+  const PT q = base + h;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) v[s] = base[h + 4 * s];
+  for (int s = 0; s < 4; ++s) v[s] = q.c(4 * s);
 }
 template <typename PT> __device__ inline void vl_store(PT base, int h, const double (&v)[4]) {
+  const PT q = base + h;
 #pragma unroll
-  for (int s = 0; s < 4; ++s) base[h + 4 * s] = v[s];
+  for (int s = 0; s < 4; ++s) q.c(4 * s) = v[s];
 }
 // Operand addressing that is valid on every lane (padding lanes read a zero block with stride 0), so
 // operand loads are unconditional and can be issued ahead of their stage.  `P` below is the base the
 // offsets refer to: the LDS workspace S, or the per-instance global stage record A (GAB layouts).
+// stage index x per-lane stride (0 on padding lanes): both far below 2^23 -> one full-rate v_mad_i32_i24 with the offset instead of a
+// quarter-rate 32-bit multiply
+__device__ inline int mul24(int a, int b) {
+#if defined(__AMDGCN__)
+  return __mul24(a, b);
+#else
+  return a * b;
+#endif
+}
 // k-major operand: lane (h,c) <- AB''[RI(s,h)][c]
 template <typename TQ> struct KMaj {
   int off[4], str[4];
@@ -540,7 +585,7 @@ template <typename TQ> struct KMaj {
   }
   template <typename PT> __device__ inline void load(PT Pb, int i, TQ (&o)[4]) const {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) o[s] = Pb[off[s] + i * str[s]];
+    for (int s = 0; s < 4; ++s) o[s] = Pb[off[s] + mul24(i, str[s])];
   }
 };
 // row-major operand: lane (h,c) <- M[c][RI(s,h)] for a row-major matrix of `rows` rows at `base` (stage stride
@@ -552,7 +597,7 @@ template <typename TQ> struct RMaj {
     str = c < rows ? sst : 0;
     hh = h;
   }
-  template <typename PT> __device__ inline void load(PT Pb, int i, TQ (&o)[4]) const { vl_load(Pb + (off + i * str), hh, o); }
+  template <typename PT> __device__ inline void load(PT Pb, int i, TQ (&o)[4]) const { vl_load(Pb + (off + mul24(i, str)), hh, o); }
 };
 // Operands are fetched PD stages ahead of their use: one stage hides the LDS latency, the global stage
 // records need more.  q[0] is the current stage; shift() retires it.
@@ -1147,12 +1192,12 @@ template <typename TQ> __device__ inline TQ pin_diag() { return sizeof(TQ) == 8 
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L PF_ARG, TQ* gscale = nullptr, P<TQ> mrows = nullptr,
-                                      P<TQ> pstore = nullptr, int start = -1) {
+                                      P<TQ> pstore = nullptr, int start = -1, bool have_rt = false) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
-  // stage input Hessian diagonals R~ (negative value = input pinned by the polish)
-  for (int i = lane; i < nv; i += 64) {
+  // stage input Hessian diagonals R~ (negative value = input pinned by the polish); have_rt: the caller has written them
+  for (int i = lane; i < nv && !have_rt; i += 64) {
     const TQ rr = S[L.wq + 2 * VS + (i & 3)];
     TQ v;
     if (!polish) v = rr + S[L.ll + i] * trcp(S[L.sl + i]) + S[L.lu + i] * trcp(S[L.su + i]);
@@ -1195,6 +1240,11 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
   const int m3off = b3 < 10 ? L.sF + b3 : L.sT + (b3 - 10) * VS + 10, m3str = b3 < 10 ? VS : 1;   // M[j][b3]
   const int tboff = b3 < 10 ? L.stv + VS + b3 : L.stv + b3;                                       // (A^T p)[b3]
   TQ cur[4], nxt[4];
+  // entry h of four values, as a two-level select on the bits of h (written as nested comparisons with h the compiler turns the
+  // polish variant into EXEC-masked branches: some 80 instructions per stage for two of these)
+  const bool hb0 = (h & 1) != 0, hb1 = (h & 2) != 0;
+  auto by_h = [&](TQ a0, TQ a1, TQ a2, TQ a3) { const TQ lo = hb0 ? a1 : a0, hi = hb0 ? a3 : a2; return hb1 ? hi : lo; };
+  const int zl = polish ? lane_zero() : 0;   // see lane_zero(): the pinned-input logic below stays on the vector ALU
   // affine: pad column 14 of the operand carries the gap (S[L.Dx], prepared by the caller), so that P c comes out of the
   // product P AB'' for free
   auto with_gap = [&](int st, TQ (&x)[4]) {
@@ -1216,7 +1266,8 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
     // what the solve needs and does not depend on this stage's products: read now, behind the tile products
     TQ rtv[4], rhov[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { rtv[a] = S[L.rt + i * NU + a]; rhov[a] = S[L.rho + i * NU + a]; }
+    for (int a = 0; a < 4; ++a) { rtv[a] = S[L.rt + i * NU + a + zl]; rhov[a] = S[L.rho + i * NU + a + zl]; }
+    const TQ rtj = polish ? S[L.rt + i * NU + vj] : TQ(0);   // the Lambda^-1 lanes: is the input whose feed-forward they store pinned
     TQ acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 4; ++s) mfma(acc1, Pop[s], cur[s]);              // T1''
@@ -1266,18 +1317,18 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
 #pragma unroll
     for (int j = 0; j < 4; ++j) mvv[j] = S[m3off + j * m3str];                                 // M[j][c]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gu[j] = rhov[j] + S[L.stv + VS + 10 + j];                        // gt = rho + B^T p
+    for (int j = 0; j < 4; ++j) gu[j] = rhov[j] + S[L.stv + VS + 10 + j + zl];                   // gt = rho + B^T p
     const TQ tb = S[tboff];
 #pragma unroll
     for (int s = 0; s < 4; ++s) tT[s] = S[toff[s]];   // transposed T1'' elements of the position columns of P_i (P update)
     // ---- Lambda = R~ + F_uu, LDL^T in registers (redundantly on every lane, straight-line code), then the solves
     TQ kk, mop, pcol;
-    int pinb = 0;
+    bool pin[4], pinany = false;             // input a of this stage is pinned (the same on every lane)
     {
-      int pinv = 0;                          // bit a: input a of this stage is pinned (the same on every lane)
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        if (polish && rtv[a] < TQ(0)) pinv |= 1 << a;   // pinned input: diagonal pin_diag (see above), zero right-hand side of the feed-forward
+        pin[a] = polish && rtv[a] < TQ(0);   // pinned input: diagonal pin_diag (see above), zero right-hand side of the feed-forward
+        pinany = pinany || pin[a];
         Lm[a][a] += polish ? tabs(rtv[a]) : rtv[a];
       }
       PF_FAC(12);                        // LDS hand-over + operand reads
@@ -1321,16 +1372,15 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
         for (int k = cc + 1; k < 4; ++k) y[cc] -= Lm[k][cc] * y[k];
       }
       // operands of the P update first: they head the chain into the next stage
-      const TQ yh = h == 0 ? y[0] : (h == 1 ? y[1] : (h == 2 ? y[2] : y[3]));
-      const TQ mh = h == 0 ? mvv[0] : (h == 1 ? mvv[1] : (h == 2 ? mvv[2] : mvv[3]));
+      const TQ yh = by_h(y[0], y[1], y[2], y[3]);
+      const TQ mh = by_h(mvv[0], mvv[1], mvv[2], mvv[3]);
       kk = c < NX ? -yh : TQ(0);
       mop = mmask * mh;
       // column lanes: K[:,c] = -y, p_i[c] = (A^T p)[c] - y.gt (+ q_i[c]); Lambda^-1 lanes: row vj = y, k_vj = -y.gt
-      pinb = polish ? __builtin_amdgcn_readfirstlane(pinv) : 0;   // as a scalar: the tests below are scalar selects / branches
       TQ dot = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const TQ gj = (pinb >> j) & 1 ? TQ(0) : gu[j];
+        const TQ gj = pin[j] ? TQ(0) : gu[j];
         dot += y[j] * gj;
         if (affine) gmax = tmax(gmax, tabs(gj));
       }
@@ -1341,7 +1391,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
       if (inv) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) Kb[L.Linv + i * 16 + vj * 4 + j] = y[j];
-        S[L.vin + i * VS + vj] = (polish && ((pinb >> vj) & 1)) ? TQ(0) : -dot;
+        S[L.vin + i * VS + vj] = (polish && rtj < TQ(0)) ? TQ(0) : -dot;
       }
     }
     PF_FAC(14);                          // right-hand sides, substitutions, stores of K, Lambda^-1
@@ -1358,10 +1408,10 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
       l2g<TQ>(pcol, h, pv);
     }
     // ---- behind the chain: what the multiplier of a pinned input j needs [M_j | F_uu row j | gt_j], the cost-to-go tile
-    if (affine && mrows && pinb) {
+    if (affine && mrows && pinany) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (!((pinb >> j) & 1)) continue;
+        if (!pin[j]) continue;
         if (h == 0 && c < NX) mrows[(i * NU + j) * MROW + c] = mvv[j];
         else if (inv && vj == j) {
 #pragma unroll
@@ -1404,8 +1454,131 @@ template <typename TQ, typename PT> __device__ inline void dbg_dump(const DevMod
 // Mehrotra predictor-corrector iterations; every Newton system is one Riccati factorisation + two
 // vector sweeps.  Continues from the current (z, sl, su, ll, lu, dx, grad) until |r_d| <= tol*gm and
 // mu <= tol.  returns 0 converged / 1 NaN / 2 iteration cap / 4 stage Hessian not positive definite
+// Shape-specialised instances with at most two inputs per lane (N <= 32; with four -- N = 50 -- the registers cost more than the
+// passes: -1.3 %): the per-input quantities of an iteration (slacks, multipliers, their reciprocals, gradient, the two directions)
+// stay in registers from one elementwise pass to the next instead of being re-read from LDS and re-derived in each of the seven
+// passes -- the same expressions on the same operands, 4 reciprocals per input and iteration instead of 16.  (The elementwise passes
+// were an eighth of an interior-point iteration: one wavefront issues an instruction every 4-5 cycles whatever it is.)  The LDS
+// copies are kept current: the sweeps read rho and R~, the polish behind reads everything.
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
+MPCQ_COLD int ipm_run_regs(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
+  constexpr int N = C::N > 0 ? C::N : 1, nv = N * NU, R = (nv + 63) / 64;
+  const int tid = lane_id();
+  int status = 2;
+  const int maxit = m.qp_max_iter;
+  bool on[R];
+  int ix[R], gi[R];
+  TQ sl[R], su[R], ll[R], lu[R], g[R], rr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + 64 * r;
+    on[r] = i < nv; ix[r] = on[r] ? i : 0; gi[r] = GI(ix[r]);
+    sl[r] = S[L.sl + ix[r]]; su[r] = S[L.su + ix[r]]; ll[r] = S[L.ll + ix[r]]; lu[r] = S[L.lu + ix[r]];
+    g[r] = S[L.grad + gi[r]]; rr[r] = S[L.wq + 2 * VS + (ix[r] & 3)];
+  }
+  for (; it < maxit; ++it) {
+    TQ rdm = 0, mu = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!on[r]) continue;
+      rdm = tmax(rdm, tabs(g[r] - ll[r] + lu[r]));
+      mu += sl[r] * ll[r] + su[r] * lu[r];
+    }
+    rdm = wave_max(rdm);
+    mu = wave_sum(mu) / (2 * nv);
+    if (!(rdm == rdm) || !(mu == mu)) { status = 1; break; }
+#ifdef MPCQ_EMU_DEBUG
+    if (tid == 0) printf("  ipm it %2d: |r_d|/gm %.3e  mu %.3e  (tol %.1e)\n", it, (double)(rdm / gm), (double)mu, (double)tol);
+#endif
+    if (rdm <= tol * gm && mu <= tol) { status = 0; break; }
+    // predictor: (H + Sigma) dza = -grad
+    TQ rsl[R], rsu[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      rsl[r] = trcp(sl[r]); rsu[r] = trcp(su[r]);
+      if (on[r]) { S[L.rho + ix[r]] = g[r]; S[L.rt + ix[r]] = rr[r] + ll[r] * rsl[r] + lu[r] * rsu[r]; }
+    }
+    __syncthreads();
+    PF_START();
+    const bool fok = riccati_factor<C, false>(m, S, A, Kb, L PF_PASS, (TQ*)nullptr, P<TQ>(nullptr), P<TQ>(nullptr), -1, true);
+    PF_STOP(PF_FACTOR);
+    if (it == 0) { DBG_DUMP(2, 0, S, L.rt, nv); DBG_DUMP(2, 128, Kb, L.K, N * KS); DBG_DUMP(2, 2048, Kb, L.Linv, N * 16); DBG_DUMP(2, 3000, S, L.vin, N * VS); }
+    if (!fok) { status = 4; break; }
+    PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dza PF_PASS); PF_STOP(PF_FWD);
+    if (it == 0) { DBG_DUMP(3, 0, S, L.dza, nv); DBG_DUMP(3, 128, S, L.Dx, (N + 1) * VS); }
+    // step lengths without divisions: alpha = 1 / max_i(-ds_i / s_i); every quotient is a product with a reciprocal
+    TQ da[R], dla[R], dua[R], rll[R], rlu[R], ainv = 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      da[r] = S[L.dza + ix[r]];
+      rll[r] = trcp(ll[r]); rlu[r] = trcp(lu[r]);
+      dla[r] = -ll[r] - ll[r] * rsl[r] * da[r]; dua[r] = -lu[r] + lu[r] * rsu[r] * da[r];
+      if (on[r]) ainv = tmax(ainv, tmax(tmax(-da[r] * rsl[r], da[r] * rsu[r]), tmax(-dla[r] * rll[r], -dua[r] * rlu[r])));
+    }
+    const TQ aff = trcp(wave_max(ainv));
+    TQ mua = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (on[r]) mua += (sl[r] + aff * da[r]) * (ll[r] + aff * dla[r]) + (su[r] - aff * da[r]) * (lu[r] + aff * dua[r]);
+    mua = wave_sum(mua) / (2 * nv);
+    TQ sigma = mua / mu;
+    sigma = sigma * sigma * sigma;
+    // corrector rhs r = -rd + rcl/sl - rcu/su ; linear term rho = -r
+    TQ rcl[R], rcu[R], rho[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      rcl[r] = -sl[r] * ll[r] + sigma * mu - da[r] * dla[r];
+      rcu[r] = -su[r] * lu[r] + sigma * mu + da[r] * dua[r];
+      const TQ rd = g[r] - ll[r] + lu[r];
+      rho[r] = rd - rcl[r] * rsl[r] + rcu[r] * rsu[r];
+      if (on[r]) S[L.rho + ix[r]] = rho[r];
+    }
+    __syncthreads();
+    PF_START(); riccati_backward_vec<C>(m, S, A, Kb, L, false); PF_STOP(PF_BWD);
+    if (it == 0) { DBG_DUMP(4, 0, S, L.rho, nv); DBG_DUMP(4, 128, S, L.vin, N * VS); }
+    PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+    if (it == 0) { DBG_DUMP(5, 0, S, L.dz, nv); DBG_DUMP(5, 128, S, L.Dx, (N + 1) * VS); }
+    TQ d[R], dl[R], du[R], apinv = 1, adinv = 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      d[r] = S[L.dz + ix[r]];
+      dl[r] = (rcl[r] - ll[r] * d[r]) * rsl[r]; du[r] = (rcu[r] + lu[r] * d[r]) * rsu[r];
+      if (on[r]) {
+        apinv = tmax(apinv, tmax(-d[r] * rsl[r], d[r] * rsu[r]));
+        adinv = tmax(adinv, tmax(-dl[r] * rll[r], -du[r] * rlu[r]));
+      }
+    }
+    const TQ tau = tmax(TQ(0.995), 1 - mu);
+    // alpha = min(1, tau / max_i(...)): the maxima start at 1, i.e. an unrestricted step has length tau
+    TQ ap = tmin(TQ(1), tau * trcp(wave_max(apinv))), ad = tmin(TQ(1), tau * trcp(wave_max(adinv)));
+#ifdef MPCQ_EMU_DEBUG
+    if (tid == 0) printf("             affine step %.3f  sigma %.2e  alpha_p %.4f  alpha_d %.4f\n", (double)aff, (double)sigma, (double)ap, (double)ad);
+#endif
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      // fp64: the gradient follows the step without a sweep (see ipm_run)
+      if (sizeof(TQ) == 8) g[r] += ap * (-rho[r] - (ll[r] * rsl[r] + lu[r] * rsu[r]) * d[r]);
+      sl[r] = sl[r] + ap * d[r]; su[r] = su[r] - ap * d[r];
+      ll[r] = ll[r] + ad * dl[r]; lu[r] = lu[r] + ad * du[r];
+      if (on[r]) {
+        S[L.z + ix[r]] += ap * d[r]; S[L.sl + ix[r]] = sl[r]; S[L.su + ix[r]] = su[r];
+        S[L.ll + ix[r]] = ll[r]; S[L.lu + ix[r]] = lu[r];
+        if (sizeof(TQ) == 8) S[L.grad + gi[r]] = g[r];
+      }
+    }
+    for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
+    __syncthreads();
+    if (sizeof(TQ) == 4) {
+      PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
+#pragma unroll
+      for (int r = 0; r < R; ++r) g[r] = S[L.grad + gi[r]];
+    }
+  }
+  return status;
+}
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
+  if constexpr (C::N > 0 && C::N * NU <= 128) return ipm_run_regs<C>(m, S, A, Kb, L, tol, gm, it PF_PASS);
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int status = 2;
   const int maxit = m.qp_max_iter;

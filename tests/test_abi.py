@@ -75,6 +75,16 @@ def test_code_objects_pass_the_exec_prologue_check():
         r_ok = subprocess.run([sys.executable, chk, ok2], capture_output=True, text=True)
         assert r_bad.returncode == 1 and "v_accvgpr_write_b32 a1, v7" in r_bad.stdout, r_bad.stdout
         assert r_ok.returncode == 0, r_ok.stdout
+    # disassembly has no labels: a join that no branch targets is merged with the `if` body in front of it.  The body's own reload
+    # (consumed inside the body) must pass, spill code directly in front of the restore must not
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_exec_prologue", chk)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    body = [("@0x10", None), (None, "v_accvgpr_read_b32 v29, a17"), (None, "global_store_dwordx4 v[28:29], v[22:25], off"), (None, "s_or_b64 exec, exec, s[24:25]")]
+    assert mod.check(body, labelled=False) == [] and mod.check(body, labelled=True) != []
+    late = [("@0x10", None), (None, "global_store_dwordx4 v[28:29], v[22:25], off"), (None, "v_accvgpr_write_b32 a1, v7"), (None, "v_writelane_b32 v9, s34, 0"),
+            (None, "s_or_b64 exec, exec, s[24:25]")]
+    assert mod.check(late, labelled=False) != []
     good = subprocess.run([sys.executable, chk, _lib.DEFAULT_LIB], capture_output=True, text=True)
     assert good.returncode == 0, good.stdout[-2000:]
     assert good.stdout.count("clean") >= 20          # every step-kernel instance of the library was looked at

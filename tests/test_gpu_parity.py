@@ -387,6 +387,9 @@ def test_matrix_cores_off_build_is_bit_identical():
     nomfma = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpc_quad_ros_amd", "libmpcq_nomfma.so")
     if not os.path.exists(nomfma):
         pytest.skip("libmpcq_nomfma.so not built (make -C mpc_quad_ros_amd/csrc variant NAME=nomfma ...)")
+    from mpc_quad_ros_amd import _lib
+    if _lib.load(nomfma).mpcq_version() != _lib.load().mpcq_version():      # the version string carries the hash of the sources
+        pytest.skip("libmpcq_nomfma.so was built from other sources than libmpcq.so (rebuild the variant)")
     B, N, nb, K = 12, 50, 50, 12
     traj, lens = swarm_trajectories(21, 0, B)
     x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))

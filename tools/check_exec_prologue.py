@@ -122,8 +122,12 @@ def kernels_from_co(path):
 SPILL_OPS = ("v_accvgpr_write", "v_accvgpr_read", "scratch_store", "scratch_load", "buffer_store", "buffer_load")
 
 
-def check(ins):
+def check(ins, labelled=True):
     """ins: [(label, text)].  A block starts at a label.  Findings: (label, instructions, why).
+    labelled = False (disassembly: block starts are the branch targets and the instructions behind branches): a join that no branch
+    targets -- the compiler drops the skip branch of a short `if` -- is merged with the body in front of it, whose own reloads (consumed
+    inside the body, under the body's EXEC: legitimate) must not count; there only the spill code DIRECTLY in front of the restore
+    counts (nothing but EXEC-independent instructions in between), which is where the misplaced prologue sits.
     - the block is the fall-through of  s_cbranch_execnz  (exit of a divergent loop: EXEC = 0): EVERY EXEC-dependent
       instruction in front of the restore is lost;
     - otherwise (end of a divergent `if`: the lanes of the branch are active) per-lane copies are legitimate there, but spill
@@ -156,7 +160,16 @@ def check(ins):
                 continue
             if re.match(r"s_or_b64 exec, exec,", t):
                 dep = [h for h in head if not h.startswith(IGNORES_EXEC)]
-                bad = dep if exec_zero else [h for h in dep if h.startswith(SPILL_OPS)]
+                if exec_zero:
+                    bad = dep
+                elif labelled:
+                    bad = [h for h in dep if h.startswith(SPILL_OPS)]
+                else:
+                    bad = []
+                    for h in reversed(dep):
+                        if not h.startswith(SPILL_OPS):
+                            break
+                        bad.insert(0, h)
                 if bad:
                     findings.append((lab, bad, "entered with EXEC = 0 (exit of a divergent loop)" if exec_zero else "spill code under the partial EXEC of a branch"))
                 break
@@ -176,7 +189,7 @@ def main(paths):
         for kind, f in code_objects(p):
             ks = kernels_from_asm(f) if kind == "asm" else kernels_from_co(f)
             for name, ins in ks.items():
-                fnd = check(ins)
+                fnd = check(ins, labelled=(kind == "asm"))
                 dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
                 dem = re.sub(r"\(mpcq::DevModel.*", "", dem)
                 if fnd:
