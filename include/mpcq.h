@@ -126,6 +126,8 @@ typedef struct mpcq_config {
 typedef struct mpcq_engine mpcq_engine;
 
 const char* mpcq_last_error(void);
+/* "mpcq <major.minor> (gfx950, source <16 hex digits>)": the digits are the hash of the sources and the build recipe the library was
+ * built from (csrc/Makefile SRC_ID = bench.kernel_source_sha16()); profiles under profiles/ carry the same hash. */
 const char* mpcq_version(void);
 
 /* ---- lifetime.  quad_optimizer.__init__ (src/quad_opt.py:36-160): builds constants, K_x^-1,
