@@ -218,6 +218,7 @@ struct EngineT : mpcq_engine {
   int* d_tlen = nullptr;
   int* d_order = nullptr;    // launch order of the lockstep periods (order_kernel); used when the batch exceeds what the device holds at once
   bool use_order = false;
+  bool split_plant = false;   // the plant update between two lockstep periods as its own launch (streaming batches), see sim_steps
   double* d_cmd = nullptr;   // [B*8] rotor thrusts, collective thrust, body rates (mpcq_get_command); also the chunk read-back
   size_t cmd_elems = 0;
   std::vector<T> hbuf;
@@ -450,6 +451,11 @@ struct EngineT : mpcq_engine {
       const int bo = ienv("MPCQ_BLOCK_ORDER", tu.block_order);
       use_order = bo == 2 || (bo == 0 && (size_t)B > resident);
       if (use_order && (rc = dalloc(d_order, Bz))) return rc;
+      // The same distinction decides where the plant update of the on-device closed loop runs (sim_steps): at the head of the next
+      // step launch (one launch per period; its RK4 substeps run on one lane of every workgroup: 6 k of a quadrotor's 172 k cycles)
+      // or as its own launch of one THREAD per quadrotor.  A resident batch waits for its slowest quadrotor, which the 2.5 us at
+      // the head hardly move, and saves a launch; a streaming batch pays those cycles in throughput.
+      split_plant = ienv("MPCQ_SPLIT_PLANT", (size_t)B > resident ? 1 : 0) != 0;
     }
     kstep = ks[layout];
     krun = kr[layout];
@@ -648,8 +654,9 @@ struct EngineT : mpcq_engine {
     while ((int)kev.size() < 2 * nev) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); kev.push_back(ev); }
     HIP_TRY(hipEventRecord(ev0, stream));
     // The plant update between two control periods rides at the head of the next step launch (MODE_PLANT_FIRST), where
-    // it overlaps that launch's global loads; only the update after the last period needs the plant kernel.
-    const bool split = false;
+    // it overlaps that launch's global loads; only the update after the last period needs the plant kernel.  Streaming batches
+    // (split_plant, see create): every update is a launch of the plant kernel.  Same arithmetic, same results either way.
+    const bool split = split_plant;
     s2.run_x = d_xs; s2.run_steps = 1; s2.run_nsub = n_sub; s2.run_dt = sim_dt;
     for (int k = 0; k < K; ++k) {
       const bool timed_launch = k % stride == 0;
