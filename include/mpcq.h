@@ -77,7 +77,7 @@ typedef enum mpcq_status {
  * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global|compact, MPCQ_GENERIC=1, MPCQ_BLOCK_ORDER override
  * the corresponding field (measurement scripts only; without MPCQ_TUNING=1 the environment is not consulted). */
 typedef struct mpcq_tuning {
-  int32_t warm_max;     /* passes of the warm active-set attempt, 1..64 (default 6 f64 / 12 f32) */
+  int32_t warm_max;     /* passes of the warm active-set attempt, 1..64 (default 12; 6 in fp64 before round 4) */
   int32_t warm_retry;   /* ... in the period after a fallback solve, 1..64 (default 1) */
   int32_t flip_max;     /* changed bound states in a fallback solve above which the next warm attempt is skipped, 1..512; -1: never (default 2) */
   int32_t abort_pins;   /* warm attempt given up when its first pass pins this many inputs, 1..512; -1: never (default 10, N/2 for N > 20) */

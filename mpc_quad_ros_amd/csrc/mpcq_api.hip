@@ -300,7 +300,9 @@ struct EngineT : mpcq_engine {
     m.polish_max = ienv("MPCQ_POLISH_MAX", tu.polish_max ? off(tu.polish_max) : (f32 ? 12 : 16));
     // passes of the warm active-set attempt before falling back to the interior point (fp64: one factorisation each, an
     // interior-point solve costs about 15 of them)
-    m.warm_max = ienv("MPCQ_WARM_MAX", tu.warm_max > 0 ? tu.warm_max : (f32 ? 12 : 6));
+    // 12 passes in both precisions since the factorisation stage of a pass costs little more than an interior-point one (round 4: 534 -> ~330
+    // instructions): 6 -> 12 is + 3-6 % on the bench workload (four seeds), + 23 % on the round-1 spline flights 150 periods in; 16 / 24 add nothing
+    m.warm_max = ienv("MPCQ_WARM_MAX", tu.warm_max > 0 ? tu.warm_max : 12);
     m.warm_retry = ienv("MPCQ_WARM_RETRY", tu.warm_retry > 0 ? tu.warm_retry : 1);
     m.ipm_margin = (T)fenv("MPCQ_IPM_MARGIN", tu.ipm_margin > 0 ? tu.ipm_margin : 0.1);
     // hand-over from the interior point: an input joins the working set when its multiplier exceeds pin_ratio x its slack.
