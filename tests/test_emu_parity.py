@@ -67,6 +67,18 @@ def test_emu_saturating_references_long_warm_attempts():
     assert sum(n for v, n in hist.items() if 3 <= v % 1000 <= 14 and v < 1000) >= 4
 
 
+def test_emu_saturating_references_any_shape_instance():
+    """The same references on the any-shape instance (tune.generic_kernel): its interior point keeps the per-input quantities in LDS
+    (ipm_run), the shape-specialised one of the tests above in registers (ipm_run_regs) -- both against the oracle, with fallback
+    solves in the run."""
+    make_g = lambda cfg: make(dataclasses.replace(cfg, tune=dict(generic_kernel=1)))
+    worst, hist, failed = pc.case_saturating_references(make_g, B=2, K=9)
+    print("saturating references, any-shape instance: worst", worst, "passes", dict(sorted(hist.items())))
+    assert failed == 0 and worst < 1e-7
+    from mpc_quad_ros_amd.engine import qp_fallback
+    assert sum(n for v, n in hist.items() if qp_fallback(v)) >= 2
+
+
 def test_emu_lane_order_independent(monkeypatch):
     # a missing barrier would make results depend on the order lanes run within a phase
     import ctypes, shutil, tempfile
