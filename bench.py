@@ -213,10 +213,12 @@ def lockstep_leg(e, n_sub, warmup, steps, dist=None):
     return t1 - t0, t_own - t0, kt / max(kl, 1)
 
 
-def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps, dist=None, keep=False):
-    """One of the other BASELINE configurations as a short lockstep leg (same workload family, pre-rolled): throughput only;
-    their parity is covered by the GPU tests."""
-    e, _cfg = make_engine(B, N, nb, prec, device, 0, 0, refs=(np.ascontiguousarray(refs[0][:B]), np.ascontiguousarray(refs[1][:B])))
+def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps, dist=None, keep=False, parity=None):
+    """One of the other BASELINE configurations as a short lockstep leg (same workload family, pre-rolled).  parity = (quads, periods):
+    the oracle check of parity_on_workload continued from the state the timed launches ended in (the f32 legs carry it: their
+    claim is the 1e-4 budget ON this workload; the f64 legs' parity is covered by the GPU tests)."""
+    refs_leg = (np.ascontiguousarray(refs[0][:B]), np.ascontiguousarray(refs[1][:B]))
+    e, _cfg = make_engine(B, N, nb, prec, device, 0, 0, refs=refs_leg)
     n_sub = e.plant_substeps(0.01, 5e-3)
     e.sim_run(preroll, n_sub, 5e-3)
     dt, dt_own, k_avg = lockstep_leg(e, n_sub, warmup, steps, dist)
@@ -228,6 +230,12 @@ def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps, dist=
            "algorithmic_gbs": algorithmic_bytes(N, nb, 8 if prec == PRECISION_F64 else 4) * B / k_avg / 1e9,
            "mean_qp_passes": float(qp_passes(its).mean()), "failed": int(((status & 7) != 0).sum()),
            "rms_pos_m": float(np.sqrt(st[0] / (3 * max(st[2], 1))))}
+    if prec == PRECISION_F32:
+        out["low_accuracy_last_step"] = int((status == 8).sum())      # MPCQ_SOLVE_LOW_ACCURACY: refinement not converged (expected 0)
+    if parity is not None:
+        r = parity_on_workload(dump_engine(e), refs_leg, N, nb, device, quads=parity[0], periods=parity[1], precision=prec)
+        out["parity_on_workload"] = {k: r[k] for k in ("max_rel_dev", "max_rel_dev_per_quad", "rgp_max_rel_dev", "quad_steps", "fallbacks", "flip_marked",
+                                                        "multi_pass", "failed", "saturated_controls", "quads", "periods", "mode")}
     if keep:
         return out, e, dt
     e.close()
@@ -679,22 +687,28 @@ def main():
             tb = time.perf_counter()
             k2, l2 = e2.get_kernel_time()
             st2 = e2.get_status()
-            out["experimental_f32" if alt == "f32" else "alt_precision"] = {"dtype": alt, "value": B * args.steps / (tb - ta), "unit": "control steps/s",
-                                    "kernel_avg_ms": 1e3 * k2 / max(l2, 1), "failed": int(((st2 & 7) != 0).sum()),
-                                    "low_accuracy_last_step": int((st2 == 8).sum()),
-                                    "note": "same workload with the QP arithmetic in the other precision.  f32 is an EXPERIMENTAL mode (include/mpcq.h states the "
-                                            "measured bounds): solves that went through the interior point or started cold are reported per instance as "
-                                            "MPCQ_SOLVE_LOW_ACCURACY (counted here for the last step).  "
-                                            "f64 is the reference's own arithmetic (<= 1e-7 vs the fp64 oracle)"}
+            leg2 = {"dtype": alt, "value": B * args.steps / (tb - ta), "unit": "control steps/s",
+                    "kernel_avg_ms": 1e3 * k2 / max(l2, 1), "failed": int(((st2 & 7) != 0).sum()),
+                    "note": "same workload, same launches, the other precision.  f32 = mixed precision (include/mpcq.h): float stage records, float Riccati "
+                            "factorisation on the matrix cores, QP solution refined against fp64 residuals; f64 = the reference's own arithmetic"}
+            if alt == "f32":
+                leg2["low_accuracy_last_step"] = int((st2 == 8).sum())      # MPCQ_SOLVE_LOW_ACCURACY: refinement not converged (expected 0)
+                if not args.no_parity:
+                    leg2["parity_on_workload"] = parity_on_workload(dump_engine(e2), refs, N, nb, local_rank, quads=64, periods=30, precision=PRECISION_F32)
+            out["f32" if alt == "f32" else "alt_precision"] = leg2
             e2.close()
         if legs:
             # the other BASELINE configurations, reachable from the driver's command: short lockstep legs after the headline
+            par = None if args.no_parity else (32, 10)
             out["configs"] = [
                 config_leg("configs[2]: batch 8192, N=20, RGP 20 basis pts", refs_cfg, 8192, 20, 20, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
+                config_leg("configs[2]: batch 8192, N=20, RGP 20 basis pts", refs_cfg, 8192, 20, 20, PRECISION_F32, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS, parity=par),
                 {k: v for k, v in swarm_out.items() if k not in ("per_rank", "efficiency_vs_best_rank", "n_gpus", "global_batch", "stats_reduce", "tracking_steps", "roofline")}
                 | {"config": f"configs[3] per rank: batch {SWARM_PER_RANK} of {SWARM_PER_RANK * 8}, N=20, RGP 10 basis pts (the `swarm` leg of this line: same pre-roll as an N > 1 run)"},
+                config_leg(f"configs[3] per rank: batch {SWARM_PER_RANK} of {SWARM_PER_RANK * 8}, N=20, RGP 10 basis pts", refs_swarm, SWARM_PER_RANK, 20, 10, PRECISION_F32, local_rank,
+                           args.preroll, SWARM_WARM, SWARM_STEPS, parity=par),
                 config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
-                config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F32, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
+                config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F32, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS, parity=par),
             ]
         if world == 1 and not args.no_parity:
             out["parity_on_workload"] = parity_on_workload(start, refs, N, nb, local_rank, quads=64, periods=30)

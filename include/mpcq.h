@@ -44,9 +44,10 @@ typedef enum mpcq_status {
 #define MPCQ_SOLVE_NAN 1          /* the QP step was not finite: the instance kept its previous iterate and control */
 #define MPCQ_SOLVE_MAXITER 2
 #define MPCQ_SOLVE_QP_FAILURE 4
-#define MPCQ_SOLVE_LOW_ACCURACY 8 /* MPCQ_PRECISION_F32 only: the step was taken, but its QP went through the interior-point fallback in
-                                     float or started cold -- outside the 1e-4 control budget, measured bounds at MPCQ_PRECISION_F32 below
-                                     (a warning, not a failure: mpcq_get_tracking_stats out[4] does not count it) */
+#define MPCQ_SOLVE_LOW_ACCURACY 8 /* MPCQ_PRECISION_F32 only: the refinement of the QP solution against fp64 residuals did not converge
+                                     (or the active-set finish behind the interior point did not settle): the step was taken with the
+                                     float answer.  Never observed; the tests require status 0 on every solve.  A warning, not a
+                                     failure: mpcq_get_tracking_stats out[4] does not count it */
 
 /* mpcq_config.flags.  MPCQ_FLAG_STATIC_GP: the GP in the model is a static one (use_gp = 1, gpe.type == "GP",
  * src/quad_opt.py:228-236 with src/gp/GP.py:136-175): basis = its training inputs, theta = (L, sigma_f,
@@ -55,17 +56,13 @@ typedef enum mpcq_status {
 #define MPCQ_FLAG_STATIC_GP 1
 
 /* MPCQ_PRECISION_F64 (default): the reference's own arithmetic; <= 1e-7 relative control deviation from the fp64 oracle.
- * MPCQ_PRECISION_F32: EXPERIMENTAL fast mode (model evaluation, sensitivities and QP solve in float; iterate, measurement
- * and QP data differences stay double).  It does NOT hold the 1e-4 budget without exceptions; what the tests measure
- * (tests/test_gpu_parity.py, teacher-forced against the fp64 oracle, relative control deviation):
- *   - solves reported with status 0 (solved from their warm start): <= 1e-4 on the six reference logs and on swarms started
- *     from hover at N = 20 and N = 50 (observed <= 2.4e-5); up to 2.1e-4 at N = 50 / nb = 50 started in flight with rotors
- *     saturated at zero thrust (asserted < 1e-3 there);
- *   - solves that went through the interior point in float ((qp_iter / 1000) % 10 != 0) AND cold-start solves (first step
- *     after create / reset) are reported with status MPCQ_SOLVE_LOW_ACCURACY instead of 0: up to 1.2e-3 on the logs
- *     (asserted < 5e-3, and at most max(6, K/12) flagged steps of a K-step log outside 1e-4), 1e-2 .. 0.2 where most inputs stay
- *     saturated (asserted < 0.5, and < 50 % of the steps flagged).
- *   The step is taken in every case; mpcq_get_tracking_stats out[4] does not count flagged steps as failures. */
+ * MPCQ_PRECISION_F32: mixed precision (round 5).  Storage and bulk arithmetic in float -- stage records (sensitivities, gaps, cost
+ * gradients), Riccati factorisation on the matrix cores, gains, sweeps, RGP state --, the accuracy of double where cond(H) ~ 2e6
+ * demands it: the iterate, the measurement and every difference that defines the QP are formed in double (as in F64), the shooting
+ * integrates in double and rounds its RECORDS to float once, and the QP solution is kept in double and refined against the residual
+ * of the QP evaluated in double on those records, the float factorisation solving for the corrections (iterative refinement).
+ * Holds the north_star budget on EVERY solve -- warm, cold start, interior-point fallback, saturated inputs: <= 1e-4 relative control
+ * deviation from the fp64 oracle, teacher-forced (tests/test_gpu_parity.py; observed <= 2.4e-5, median 2e-8 .. 4e-7), status 0. */
 #define MPCQ_PRECISION_F64 0
 #define MPCQ_PRECISION_F32 1
 

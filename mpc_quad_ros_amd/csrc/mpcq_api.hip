@@ -408,7 +408,7 @@ struct EngineT : mpcq_engine {
     kr[0] = &mpcq::step_kernel<mpcq::Cfg<T, false, 0, -1, true>>; kr[1] = &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true>>;
     kr[2] = &mpcq::step_kernel<mpcq::Cfg<T, true, 0, -1, true, true>>;
     for (int l = 0; l < 3; ++l) {
-      Ls[l] = mpcq::lds_layout(N, nb, l);
+      Ls[l] = mpcq::lds_layout(N, nb, l, sizeof(T) == 4);
       bytes[l] = mpcq::lds_bytes<T>(Ls[l]);
       // lockstep launches: shape-specialised instances (compile-time N and nb), from mpcq_spec.hip
       if (!generic)

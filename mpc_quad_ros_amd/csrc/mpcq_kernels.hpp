@@ -288,6 +288,7 @@ struct DevState {
 // [q(4) v(3) r(3) p(3)] (position last) and a stride of 16.
 struct Lds {
   int X, U, x0, pre, dbytes;
+  int zd, dxd;               // mixed precision (TQ = float): the QP solution and its state trajectory in double (refined against fp64 residuals)
   int AB, c, qv, r0, lb, ub, alpha, basis, wq;
   int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv;
   int sub, rgp, qtotal;
@@ -300,7 +301,8 @@ __host__ __device__ inline int al4(int v) { return (v + 3) & ~3; }
 // gab: 0 everything in LDS | 1 the stage records (AB'', c, qv) in the per-instance global record | 2 = 1 + the Riccati gains there too
 // and the QP vectors r0 / lb / ub inside the union region (the "compact" layout of large batches: six instead of four quadrotors
 // per CU in fp64 at N = 20, i.e. a second wave on two of the four SIMDs).
-__host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
+// mixed: the instance computes in float and refines its QP solution against residuals evaluated in double (TQ = float)
+__host__ __device__ inline Lds lds_layout(int N, int nb, int gab, int mixed = 0) {
   Lds L;
   int o = 0, g = 0;
   L.gk = gab == 2 ? 1 : 0;
@@ -311,6 +313,8 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab) {
   L.U = take(N * NU);
   L.x0 = take(NX + 8);   // + [v_body(3), a_drag(3)] scratch of the post phase
   L.pre = take(NX + 5);  // what the post phase reads of the persistent state, fetched in the load phase: x_pred_prev(13) | statistics(4) | has_prev
+  L.zd = L.dxd = 0;
+  if (mixed) { L.zd = take(N * NU); L.dxd = take((N + 1) * VS); }
   L.dbytes = o * 8;
   o = 0;
   const int nv = N * NU;
@@ -497,7 +501,9 @@ template <typename TQ> __device__ inline int RI(int s, int h) { return sizeof(TQ
 // A vector held lane-indexed (lane (h,c) holds x[c], the same in every row h) -> group-uniform operand form (every lane of row
 // h holds x[RI(s,h)], s = 0..3) without LDS: rotate row h left by U*h lanes (two conditional row_ror; U = 1 for the f64 slot
 // map h + 4s, 4 for the f32 map 4h + s), then row_newbcast of the lane that now holds the slot.
-template <typename TQ> __device__ inline void l2g(TQ x, int h, TQ (&v)[4]) {
+// (TQ selects the slot map -- the storage type of the matrix operand --, TV is the type of the vector: the mixed-precision sweeps
+//  multiply float operands by a double vector)
+template <typename TQ, typename TV> __device__ inline void l2g(TV x, int h, TV (&v)[4]) {
   if (sizeof(TQ) == 8) {
     x = dpp_rows<0x12F, 0xA>(x, h);            // rows 1, 3: row_ror:15 -> lane c <- lane c + 1
     x = dpp_rows<0x12E, 0xC>(x, h);         // rows 2, 3: row_ror:14 -> lane c <- lane c + 2
@@ -837,11 +843,24 @@ template <typename C, typename M> __device__ inline int cNB(const M& m) { return
 // ------------------------------------------------------------------ shooting
 // pass 1: lane (triple) per interval, 4 RK substages in TQ; writes records + gap c_i = Phi_i - X_{i+1}
 // (the part X_i - X_{i+1} of the gap is formed in double)
+// TS: arithmetic of the integration.  The float instances integrate in double too (MPCQ_MIXED_SHOOT64) and round the RECORDS to
+// float: their QP solution is refined against fp64 residuals of the stored stage data, so what is left of the 1e-4 budget goes to
+// the data themselves -- records computed in float carry ~1e-6 relative error, which a saturated quadrotor far off its reference
+// (gradient scale 3e4) turns into 2e-4 .. 7e-4 of control deviation; computed in double and rounded once it is the 6e-8 of the storage.
+// The GP sums stay in TQ (the exps of the basis): benign in float.
+#ifndef MPCQ_MIXED_SHOOT64
+#define MPCQ_MIXED_SHOOT64 1
+#endif
+template <typename TQ> struct ShootT { using T = TQ; };
+#if MPCQ_MIXED_SHOOT64
+template <> struct ShootT<float> { using T = double; };
+#endif
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, const Lds& L, bool gp) {
+  using TS = typename ShootT<TQ>::T;
   const int N = cN<C>(m), lane = lane_id();
-  const QC<TQ> qc(m);
-  const TQ h = (TQ)m.h;
+  const QC<TS> qc(m);
+  const TS h = (TS)m.h;
   // with the GP in the model the three axis sums (nb exps each) of a stage go to three neighbouring lanes
   const int per = gp ? 3 : 1, lanes_used = gp ? 63 : 64, spr = lanes_used / per;   // stages per round
   P<TQ> gx = S + (L.gx + (lane / 3) * 8);   // LDS exchange scratch
@@ -850,19 +869,19 @@ MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> 
     const bool valid = lane < lanes_used && base + il < N;
     const int i = valid ? base + il : 0;
     const int gd = gp ? (lane < lanes_used ? d : 0) : -1;
-    TQ x[NX], u[NU], k[NX], xt[NX], acc[NX];
+    TS x[NX], u[NU], k[NX], xt[NX], acc[NX];
 #pragma unroll
-    for (int j = 0; j < NX; ++j) x[j] = (TQ)D[L.X + i * NX + j];
+    for (int j = 0; j < NX; ++j) x[j] = (TS)D[L.X + i * NX + j];
 #pragma unroll
-    for (int j = 0; j < NU; ++j) u[j] = (TQ)D[L.U + i * NU + j];
+    for (int j = 0; j < NU; ++j) u[j] = (TS)D[L.U + i * NU + j];
     const P<TQ> al = gp ? S + L.alpha : P<TQ>(nullptr);
     const P<TQ> sub = (valid && d == 0) ? S + (L.sub + i * SUBS) : P<TQ>(nullptr);
 #pragma unroll
     for (int j = 0; j < NX; ++j) { acc[j] = 0; xt[j] = x[j]; }
     MPCQ_RK_LOOP
     for (int s = 0; s < 4; ++s) {   // acc = k1 + 2 k2 + 2 k3 + k4, next point x + {h/2, h/2, h} k
-      model_eval<TQ, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + s * SUBW : P<TQ>(nullptr), gd, gx);
-      const TQ wa = (s == 0 || s == 3) ? TQ(1) : TQ(2), hc = s == 2 ? h : h / 2;
+      model_eval<TS, TQ>(qc, cNB<C>(m), m.L2inv, m.sf2, xt, u, al, S + L.basis, k, sub ? sub + s * SUBW : P<TQ>(nullptr), gd, gx);
+      const TS wa = (s == 0 || s == 3) ? TS(1) : TS(2), hc = s == 2 ? h : h / 2;
 #pragma unroll
       for (int j = 0; j < NX; ++j) { acc[j] += wa * k[j]; xt[j] = x[j] + hc * k[j]; }
     }
@@ -875,10 +894,9 @@ MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> 
     }
   }
 }
-// pass 2: item = (interval i, column j of [A|B], j = 3..16) -> AB'[i][r][j-3]
-template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L) {
-  const int N = cN<C>(m);
+// pass 2: item = (interval i, column j of [A|B], j = 3..16) -> AB'[i][r][j-3]; arithmetic TQ, records TR
+template <typename C, typename TQ, typename TR, typename M>
+__device__ inline void shoot_sens_t(const M& m, P<TR> S, P<TR> A, const Lds& L, const int N) {
   const QC<TQ> qc(m);
   const TQ h = (TQ)m.h;
   const TQ c10 = (qc.J[1] - qc.J[2]) * qc.iJ[0], c11 = (qc.J[2] - qc.J[0]) * qc.iJ[1], c12 = (qc.J[0] - qc.J[1]) * qc.iJ[2];
@@ -895,12 +913,12 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L
       if (j - NX == c) { jur[0] = qc.tmax * qc.yf[c] * qc.iJ[0]; jur[1] = -qc.tmax * qc.xf[c] * qc.iJ[1]; jur[2] = qc.tmax * qc.zl[c] * qc.iJ[2]; }
     MPCQ_SENS_LOOP
     for (int s = 0; s < 4; ++s) {
-      const P<TQ> sub = S + (L.sub + i * SUBS + s * SUBW);
+      const P<TR> sub = S + (L.sub + i * SUBS + s * SUBW);
       const TQ hs = s == 0 ? TQ(0) : (s == 3 ? h : h * TQ(0.5)), ws = (s == 0 || s == 3) ? TQ(1) : TQ(2);
 #pragma unroll
       for (int r = 0; r < NX; ++r) Z[r] = ((r == j) ? TQ(1) : TQ(0)) + hs * Sp[r];
-      const TQ qw = sub[SUB_Q], qx = sub[SUB_Q + 1], qy = sub[SUB_Q + 2], qz = sub[SUB_Q + 3];
-      const TQ r0 = sub[SUB_R], r1 = sub[SUB_R + 1], r2 = sub[SUB_R + 2];
+      const TQ qw = (TQ)sub[SUB_Q], qx = (TQ)sub[SUB_Q + 1], qy = (TQ)sub[SUB_Q + 2], qz = (TQ)sub[SUB_Q + 3];
+      const TQ r0 = (TQ)sub[SUB_R], r1 = (TQ)sub[SUB_R + 1], r2 = (TQ)sub[SUB_R + 2];
       TQ Sn[NX];
       Sn[0] = Z[7]; Sn[1] = Z[8]; Sn[2] = Z[9];
       Sn[3] = TQ(0.5) * (-r0 * Z[4] - r1 * Z[5] - r2 * Z[6] - qx * Z[10] - qy * Z[11] - qz * Z[12]);
@@ -909,11 +927,11 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L
       Sn[6] = TQ(0.5) * (r2 * Z[3] + r1 * Z[4] - r0 * Z[5] - qy * Z[10] + qx * Z[11] + qw * Z[12]);
 #pragma unroll
       for (int row = 0; row < 3; ++row) {
-        TQ t = ucol ? sub[SUB_RZ + row] * tm : TQ(0);
+        TQ t = ucol ? (TQ)sub[SUB_RZ + row] * tm : TQ(0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) t += sub[SUB_JQ + row * 4 + c] * Z[3 + c];
+        for (int c = 0; c < 4; ++c) t += (TQ)sub[SUB_JQ + row * 4 + c] * Z[3 + c];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) t += sub[SUB_JV + row * 3 + c] * Z[7 + c];
+        for (int c = 0; c < 3; ++c) t += (TQ)sub[SUB_JV + row * 3 + c] * Z[7 + c];
         Sn[7 + row] = t;
       }
       Sn[10] = jur[0] + c10 * (r2 * Z[11] + r1 * Z[12]);
@@ -922,13 +940,18 @@ MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L
 #pragma unroll
       for (int r = 0; r < NX; ++r) { acc[r] += ws * Sn[r]; Sp[r] = Sn[r]; }
     }
-    const P<TQ> AB = A + (L.AB + i * ABS);
+    const P<TR> AB = A + (L.AB + i * ABS);
 #pragma unroll
-    for (int r = 0; r < NX; ++r) AB[o2i(r) * ABW + jp] = st16(((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r]);
+    for (int r = 0; r < NX; ++r) AB[o2i(r) * ABW + jp] = st16((TR)(((r == j) ? TQ(1) : TQ(0)) + h / 6 * acc[r]));
   }
   // zero the two pad columns (read by the vectorised 4-wide loads)
   for (int it = lane_id(); it < N * NX * 2; it += 64) A[L.AB + (it >> 1) * ABW + 14 + (it & 1)] = 0;
   for (int it = lane_id(); it < N * 3; it += 64) A[L.c + (it / 3) * VS + NX + it % 3] = 0;
+}
+
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
+MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L) {
+  shoot_sens_t<C, typename ShootT<TQ>::T, TQ>(m, S, A, L, cN<C>(m));   // (arithmetic: see shoot_states)
 }
 
 // ------------------------------------------------------------------ QP: vector sweeps
@@ -2060,6 +2083,261 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ
   return settled;
 }
 
+// ------------------------------------------------------------------ mixed precision (TQ = float): fp64 residuals on the float stage records
+// The float Riccati factorisation is a preconditioner: cond(H) ~ 2e6, so a solve in float alone carries 1e-5 .. 1e-2 of error in du
+// (hard part 1b).  The solution is therefore kept in double (D[L.zd], D[L.dxd]) and refined against the residual
+// of the QP evaluated in DOUBLE arithmetic on the stored (float) stage records -- state rollout and gradient sweep below, the same
+// operand registers as the float sweeps with the float slot map, the vector in double -- with the float factorisation solving for
+// the corrections: classical iterative refinement, contraction ~ cond x eps32 per step, limit = the exact solution of the QP the
+// records define.
+// state trajectory of D[L.zd]: dxd_{i+1} = A dxd_i + B zd_i + c_i from D[L.dxd + 0..15] = dx_0
+template <typename C, bool GAB = C::GAB>
+MPCQ_PHASE void rollout64(const DevModel<float>& m, P<double> D, P<float> S, P<float> A, const Lds& L) {
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
+  const RMaj<float> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
+  constexpr int PD = Depth<GAB>::PD;
+  const bool prow = c >= 10 && c < NX;
+  // float slot map: lane row h multiplies slots 4h .. 4h+3 -- states below 10, inputs 0,1 in registers 2,3 of row 2, inputs 2,3 in
+  // registers 0,1 of row 3 (slots 14, 15 are the zero pad columns of AB'')
+  const int zo = L.zd + (h == 3 ? 2 : 0);
+  double xc = D[L.dxd + c];
+  float qa[PD + 1][4], qc[PD + 1];
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int id = d < N ? d : N - 1;
+    rm.load(A, id, qa[d]);
+    qc[d] = A[L.c + id * VS + c];
+  }
+#pragma unroll MPCQ_UNROLL_SWEEP
+  for (int i = 0; i < N; ++i) {
+    const int ip = i + PD < N ? i + PD : N - 1;
+    rm.load(A, ip, qa[PD]);
+    qc[PD] = A[L.c + ip * VS + c];
+    const double z0 = D[zo + i * NU], z1 = D[zo + i * NU + 1];
+    double xv[4];
+    l2g<float>(xc, h, xv);
+    const double v0 = h == 3 ? z0 : xv[0], v1 = h == 3 ? z1 : xv[1];
+    const double v2 = h < 2 ? xv[2] : (h == 2 ? z0 : 0.0), v3 = h < 2 ? xv[3] : (h == 2 ? z1 : 0.0);
+    const double t = hsum(((double)qa[0][0] * v0 + (double)qa[0][1] * v1) + ((double)qa[0][2] * v2 + (double)qa[0][3] * v3));
+    double xn = t + (prow ? xc : 0.0) + (double)qc[0];
+    xn = c < NX ? xn : 0.0;
+    xc = xn;
+    if (lane < VS) D[L.dxd + (i + 1) * VS + lane] = xn;
+    shift<float, PD>(qa);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) qc[d] = qc[d + 1];
+  }
+  __syncthreads();
+}
+// gradient of the QP objective at (dxd(zd), zd) in double, rounded to float into S[L.grad] (the right-hand side of the correction
+// solve; the multipliers of the pinned inputs); gF = largest |gradient| over the free inputs, vmax = worst wrong-signed multiplier
+// of a pinned one, both from the double values
+template <typename C, bool GAB = C::GAB>
+MPCQ_PHASE void adjoint64(const DevModel<float>& m, P<double> D, P<float> S, P<float> A, const Lds& L, double& gF, double& vmax) {
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
+  const KMaj<float> km(L, N, h, c);
+  constexpr int PD = Depth<GAB>::PD;
+  const bool arow = c < 10, prow = c >= 10 && c < NX, ucol = c >= 10 && c < 14;
+  const int j = ucol ? c - 10 : 0;
+  const double qdc = (double)S[L.wq + c], ru = (double)S[L.wq + 2 * VS + j];
+  double pc = (double)S[L.wq + VS + c] * D[L.dxd + N * VS + c] + (double)A[L.qv + N * VS + c];
+  float qa[PD + 1][4], qq[PD + 1];
+  double gf = 0, vm = 0;
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int id = N - 1 - d > 0 ? N - 1 - d : 0;
+    km.load(A, id, qa[d]);
+    qq[d] = A[L.qv + id * VS + c];
+  }
+#pragma unroll MPCQ_UNROLL_SWEEP
+  for (int i = N - 1; i >= 0; --i) {
+    const int ip = i - PD > 0 ? i - PD : 0;
+    km.load(A, ip, qa[PD]);
+    qq[PD] = A[L.qv + ip * VS + c];
+    const double dxc = D[L.dxd + i * VS + c];
+    // local part of the input gradient: R z + r0 (r0 = R (U - uref), formed in double by the load phase and rounded to float once)
+    const double gvc = ucol ? ru * D[L.zd + i * NU + j] + (double)S[L.r0 + i * NU + j] : 0.0;
+    const float a = S[L.act + i * NU + j];
+    double pi[4];
+    l2g<float>(pc, h, pi);
+    const double t = hsum(((double)qa[0][0] * pi[0] + (double)qa[0][1] * pi[1]) + ((double)qa[0][2] * pi[2] + (double)qa[0][3] * pi[3]));   // (AB''^T p)[c]
+    const double g = t + gvc;
+    if (lane < VS) S[L.grad + i * VS + lane] = (float)g;
+    if (ucol) {
+      double ag = fabs(g);
+      if (!(ag == ag)) ag = 1e308;   // not a number: reported as an overflowing residual (the caller tests gF < 1e300)
+      if (a == 0.0f) gf = ag > gf ? ag : gf;
+      else { const double v = a < 0.0f ? -g : g; vm = v > vm ? v : vm; gf = ag >= 1e308 ? ag : gf; }
+    }
+    pc = (arow ? t : (prow ? pc : 0.0)) + (qdc * dxc + (double)qq[0]);
+    shift<float, PD>(qa);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) qq[d] = qq[d + 1];
+  }
+  __syncthreads();
+  gF = wave_max(gf);
+  vmax = wave_max(vm);
+}
+
+// Active-set method of the mixed-precision mode (TQ = float): the working-set logic of polish_incremental -- affine first pass of a warm
+// attempt, Newton steps of the float factorisation with a ratio test, pins, releases -- with the iterate in double (D[L.zd]) and every
+// residual evaluated in double (rollout64 / adjoint64).  A pass at a minimiser candidate (no pin in the step that led to it) is one
+// step of iterative refinement; the method settles when the correction it takes is below tol_c (the remaining error is that times the
+// contraction, a few per cent) or when the residual says the previous one already was.  Multiplier signs are judged on the double
+// values.  On success D[L.zd], D[L.dxd] hold the solution, S[L.z] its float image.
+#ifndef MPCQ_MIXED_TOLC
+#define MPCQ_MIXED_TOLC 1e-5
+#endif
+template <typename C, bool GAB = C::GAB>
+MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, P<float> A, P<float> Kb, const Lds& L, float gm, int& passes, const bool warm,
+                             const int max_passes, int& why, int& converged, const bool last_resort PF_ARG) {
+  using TQ = float;
+  why = QPX_BUDGET;
+  converged = 1;
+  const int N = cN<C>(m), nv = N * NU, tid = lane_id();
+  auto lbd = [&](int i) { return m.ulb[i & 3] - D[L.U + i]; };   // bounds of du in double (S[L.lb], S[L.ub] are their float images)
+  auto ubd = [&](int i) { return m.uub[i & 3] - D[L.U + i]; };
+  if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
+    for (int i = tid; i < nv; i += 64) {
+      S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
+      D[L.zd + i] = 0;
+    }
+  } else {      // working set identified by the interior point, which is also the starting point
+    for (int i = tid; i < nv; i += 64) {
+      S[L.act + i] = S[L.ll + i] > m.pin_ratio * S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > m.pin_ratio * S[L.su + i] ? TQ(1) : TQ(0));
+      D[L.zd + i] = (double)S[L.z + i];
+    }
+  }
+  if (tid < VS) D[L.dxd + tid] = tid < NX ? D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)] : 0.0;   // dx_0 = x_meas - X_0, not rounded to float
+  __syncthreads();
+  double tolm = 1e-8 * (double)gm;   // multiplier sign test (on double residuals)
+  const double tolb = 16 * (double)m.eps;   // bound proximity of a pin (bounds are O(1))
+  const double tol_c = MPCQ_MIXED_TOLC, tol_z = 1e-6;
+  bool refactor = true, settled = false, full = false, released = false;
+  int nact = 1, careful = 0;
+  double gF_prev = -1, dz_prev = 0;   // residual and correction of the previous refinement step on this working set (< 0: none)
+  for (passes = 0; passes < max_passes; ++passes) {
+    const bool aff = warm && passes == 0;
+    bool corrected = false;
+    double gF = 0, vmax = 0;
+    if (aff) {
+      // Warm start from z = 0 with every pinned input at a bound of exactly 0: the minimiser on the working set is the solution of the
+      // affine LQ problem itself (gaps c_i, gradients q_i, r_i in the recursion): one factorisation and one forward sweep.
+      int na = 0;
+      for (int i = tid; i < nv; i += 64) { S[L.rho + i] = S[L.r0 + i]; na += S[L.act + i] != TQ(0) ? 1 : 0; }
+      nact = wave_sum(na);
+      for (int it = tid; it < N * VS; it += 64) S[L.Dx + it] = (it & 15) < NX ? A[L.c + it] : TQ(0);
+      __syncthreads();
+      PF_START();
+      TQ gfac = 0;
+      const bool fok = riccati_factor<C, true, true>(m, S, A, Kb, L PF_PASS, &gfac);
+      PF_STOP(PF_FACTOR);
+      if (!fok) { why = QPX_NUMERIC; return false; }
+      gm = tmax(TQ(1), gfac);
+      tolm = 1e-8 * (double)gm;
+      refactor = false;
+      PF_START(); riccati_forward<C, true>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+    } else {
+      int na = 0;
+      for (int i = tid; i < nv; i += 64) {
+        const TQ a = S[L.act + i];
+        if (a < 0) D[L.zd + i] = lbd(i);
+        else if (a > 0) D[L.zd + i] = ubd(i);
+        na += a != TQ(0) ? 1 : 0;
+      }
+      nact = wave_sum(na);
+      __syncthreads();
+      PF_START(); rollout64<C>(m, D, S, A, L); PF_STOP(PF_ROLL);
+      PF_START(); adjoint64<C>(m, D, S, A, L, gF, vmax); PF_STOP(PF_ADJ);
+      if (!(gF < 1e300)) { why = QPX_NUMERIC; return false; }
+#ifdef MPCQ_EMU_DEBUG
+      if (tid == 0) printf("  mixed pass %d warm %d full %d gF %.3e vmax %.3e tolm %.3e nact %d (prev gF %.3e dz %.3e)\n", passes, (int)warm, (int)full, gF, vmax, tolm, nact, gF_prev, dz_prev);
+#endif
+      bool rel_now = false;
+      if (full) {   // the point minimises the QP on the working set up to the error under refinement: multipliers are meaningful
+        if (vmax > tolm) {
+          const double rel_thr = careful == 0 ? 0.0 : (careful == 1 ? 0.25 * vmax : (careful == 2 ? 0.625 * vmax : vmax));
+          for (int i = tid; i < nv; i += 64) {
+            const TQ a = S[L.act + i];
+            const double g = (double)S[L.grad + GI(i)], v = a < 0 ? -g : g;
+            if (a != TQ(0) && v > tolm && v >= rel_thr) S[L.act + i] = 0;   // release wrong-signed multipliers
+          }
+          refactor = true;
+          rel_now = true;
+          __syncthreads();
+        } else if (gF == 0.0 || (gF_prev > 0 && dz_prev * (gF / gF_prev) <= tol_z)) {
+          settled = true;   // the previous correction left less than tol_z (its size times the contraction the residual shows)
+          break;
+        } else if (gF_prev > 0 && gF > 0.5 * gF_prev) {
+          converged = 0;    // refinement stagnates (never observed: cond x eps32 < 1): accepted and reported
+          settled = true;
+          break;
+        }
+      }
+      released = rel_now;
+      if (rel_now) gF_prev = -1;
+      for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
+      __syncthreads();
+      PF_START();
+      if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, Kb, L PF_PASS); PF_STOP(PF_FACTOR); if (!fok) { why = QPX_NUMERIC; return false; } }
+      else { riccati_backward_vec<C>(m, S, A, Kb, L, true); PF_STOP(PF_BWD); }
+      refactor = false;
+      PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+      corrected = full && !rel_now;
+    }
+    // full Newton step; if it leaves the box, clip and pin EVERY violator at once
+    int viol = 0;
+    double dzm = 0;
+    for (int i = tid; i < nv; i += 64) {
+      if (S[L.act + i] != TQ(0)) continue;
+      const double d = (double)S[L.dz + i], zn = D[L.zd + i] + d;
+      if (!(zn == zn)) viol |= 2;
+      if (zn < lbd(i) || zn > ubd(i)) viol |= 1;
+      dzm = fabs(d) > dzm ? fabs(d) : dzm;
+    }
+    viol = wave_reduce(viol, [](int a, int b) { return a | b; });
+    if (viol & 2) { why = QPX_NUMERIC; return false; }
+    dzm = wave_max(dzm);
+    int nblk = 0;
+    for (int i = tid; i < nv; i += 64) {
+      if (S[L.act + i] != TQ(0)) continue;
+      const double lb = lbd(i), ub = ubd(i);
+      double z = D[L.zd + i] + (double)S[L.dz + i];
+      if (viol) {
+        if (z <= lb + tolb) { z = lb; S[L.act + i] = -1; nblk += 1; }
+        else if (z >= ub - tolb) { z = ub; S[L.act + i] = 1; nblk += 1; }
+      }
+      D[L.zd + i] = z;
+    }
+    nblk = wave_sum(nblk);
+#ifdef MPCQ_EMU_DEBUG
+    if (tid == 0) printf("     step %.3e nblk %d corrected %d\n", dzm, nblk, (int)corrected);
+#endif
+    full = nblk == 0;
+    // wholesale bounce in a saturated regime: leave it to the interior point (not behind its final iterations: last_resort)
+    if (released && nblk >= 8 && 2 * (nact + nblk) >= nv && !last_resort) { why = QPX_BOUNCE; return false; }
+    if (nblk > 0) { refactor = true; gF_prev = -1; if (released && careful < 3) careful += 1; }
+    released = false;
+    if (corrected && full) {
+      if (dzm <= tol_c) {   // the state trajectory follows the correction (the sweep's own Dx)
+        for (int it = tid; it < (N + 1) * VS; it += 64) D[L.dxd + it] += (double)S[L.Dx + it];
+        settled = true; passes += 1;
+        break;
+      }
+      gF_prev = gF; dz_prev = dzm;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (settled)
+    for (int i = tid; i < nv; i += 64) {
+      const TQ a = S[L.act + i];
+      S[L.z + i] = a < 0 ? S[L.lb + i] : (a > 0 ? S[L.ub + i] : (TQ)D[L.zd + i]);
+    }
+  __syncthreads();
+  return settled;
+}
+
 // Box-QP solve.  (1) Warm active-set attempt: the RTI iterate is persisted, so the working set of the
 // previous control step (inputs sitting exactly on a bound) is usually still optimal or off by one or two
 // inputs; a few passes of the active-set method from z = 0 then end on the exact KKT point at the cost of
@@ -2069,11 +2347,18 @@ MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ
 // the same unique optimum.  On exit S[L.z] holds the solution and S[L.dx] the matching state trajectory;
 // returns passes (+1000 when the warm attempt had to fall back).
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const Lds& L, int* status, const int prev_iter, int* work PF_ARG) {
+MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<TQ> G, const Lds& L, int* status, const int prev_iter, int* work PF_ARG) {
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   int it = 0, passes = 0, wpasses = 0, why = 0;
   TQ gm = 1;
   const P<TQ> Kb = C::GK ? G : S;   // where the gains live
+  // the active-set method of the precision: fp64 -- one affine solve per working set (polish); float -- the mixed-precision method
+  // (polish_mixed: float factorisation, iterate and residuals in double).  conv: 0 when its refinement did not converge.
+  int conv = 1;
+  auto active_set = [&](TQ g, int& np, const bool warm, const int cap, int& wy, const bool last_resort = false) -> bool {
+    if constexpr (sizeof(TQ) == 8) return polish<C>(m, S, A, G, L, g, np, warm, cap, wy PF_PASS);
+    else return polish_mixed<C>(m, D, S, A, Kb, L, g, np, warm, cap, wy, conv, last_resort PF_PASS);
+  };
   // prev_iter: this quadrotor's previous return value (0: cold start).  Decimal fields (qp_iter of include/mpcq.h):
   //   passes + interior-point iterations | x 1000: the warm attempt was given up or skipped (fallback solve) |
   //   x 10000: flip mark | x 100000: why the warm attempt ended (QPX_*).
@@ -2088,9 +2373,8 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const 
   const int warm_cap = flipping ? 0 : ((prev_iter / 1000) % 10 != 0 ? m.warm_retry : m.warm_max);
   if (flipping) { wpasses = 1000; why = QPX_SKIPPED; }   // counts as a fallback solve
   if (prev_iter > 0 && warm_cap > 0) {
-    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap, why PF_PASS)
-                        : polish_incremental<C>(m, S, A, Kb, L, gm, wpasses, true, warm_cap, why PF_PASS)) {   // sets z = 0 and its own gradient scale
-      *status = 0;
+    if (active_set(gm, wpasses, true, warm_cap, why)) {   // sets z = 0 and its own gradient scale
+      *status = conv ? 0 : 8;
       *work = wpasses | (wpasses << 16);   // one (possibly resumed) factorisation and one forward sweep per pass
       return wpasses;
     }
@@ -2119,18 +2403,44 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const 
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
     int why2 = 0;
-    if (sizeof(TQ) == 8 ? polish<C>(m, S, A, G, L, gm, passes, false, m.polish_max, why2 PF_PASS)
-                        : polish_incremental<C>(m, S, A, Kb, L, gm, passes, false, m.polish_max, why2 PF_PASS)) need_roll = false;
+    if (active_set(gm, passes, false, m.polish_max, why2)) need_roll = false;
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
       PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
       PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
       st = ipm_run<C>(m, S, A, Kb, L, m.qp_tol, gm, it PF_PASS);
+      if constexpr (sizeof(TQ) == 4) {
+        // float: the interior point's own answer is good to ~sqrt(eps32) on weakly active inputs only.  Its working set at the final
+        // tolerance is (nearly) the optimal one: the active-set method once more from there, without the early exit, ends on the
+        // solution refined against fp64 residuals; only if that fails too is the interior point's answer taken -- and reported.
+        if (st == 0) {
+          for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
+          __syncthreads();
+          int p2 = 0, why3 = 0;
+          if (active_set(gm, p2, false, 2 * m.polish_max, why3, true)) need_roll = false;
+          else {
+            for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
+            __syncthreads();
+            conv = 0;
+          }
+          passes += p2;
+        }
+      }
     }
   }
-  if (need_roll) { PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
-  *status = st;
+  if (need_roll) {   // state trajectory of the returned z (the interior point's own answer: the active-set method did not settle)
+    PF_START();
+    if constexpr (sizeof(TQ) == 8) rollout<C>(m, S, A, L, L.dx, L.z, true);
+    else {
+      for (int i = tid; i < nv; i += 64) D[L.zd + i] = (double)S[L.z + i];
+      if (tid < VS) D[L.dxd + tid] = tid < NX ? D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)] : 0.0;
+      __syncthreads();
+      rollout64<C>(m, D, S, A, L);
+    }
+    PF_STOP(PF_ROLL);
+  }
+  *status = (st == 0 && !conv) ? 8 : st;
   // bound states that differ between the previous solution (z = 0: on a bound where lb or ub is 0) and this one
   int chg = 0;
   if (m.flip_max >= 0 && prev_iter > 0) {
@@ -2228,7 +2538,7 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   const int tid = lane_id();
   const int N = cN<C>(m), nb = cNB<C>(m), nv = N * NU;
   const int b = st.order ? st.order[blockIdx.x] : (int)blockIdx.x;
-  const Lds L = lds_layout(N, nb, C::LAYOUT);
+  const Lds L = lds_layout(N, nb, C::LAYOUT, sizeof(TQ) == 4);
 #ifdef MPCQ_CHECKED
   if (tid == 0) *reinterpret_cast<int**>(smem_raw) = st.chk;   // where violations are recorded (ck_rec)
   if (tid == 0 && b == 0 && st.chk) { const unsigned long long pc = __builtin_amdgcn_s_getpc(); st.chk[9] = (int)(unsigned)pc; st.chk[10] = (int)(unsigned)(pc >> 32); }
@@ -2399,7 +2709,7 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   int status = 0;
   const int prev_iter = st.qp_iter[b];
   int work = 0;
-  const int iters = solve_qp<C>(m, S, A, G, L, &status, prev_iter, &work PF_PASS);
+  const int iters = solve_qp<C>(m, D, S, A, G, L, &status, prev_iter, &work PF_PASS);
 #ifdef MPCQ_TRACE_NAN
   trace(2, nonfinite(S, L.z, nv) | nonfinite(S, L.dx, (N + 1) * VS) << 1 | (unsigned long long)(status & 0xff) << 8 | (unsigned long long)(unsigned)iters << 32);
 #endif
@@ -2407,19 +2717,22 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   // ---- 3. full step (iterate accumulated in double).  A step that is not finite (a QP that broke down: only seen
   //      with the fp32 QP on infeasible references) is not taken: the iterate and the control of the previous period
   //      stay, the instance reports MPCQ_SOLVE_NAN and starts the next period from a sound iterate.
+  // (float instances hand the QP solution over in double: D[L.dxd], D[L.zd], refined against fp64 residuals)
+  auto sol_dx = [&](int k) -> double { if constexpr (sizeof(TQ) == 4) return D[L.dxd + k]; else return (double)S[L.dx + k]; };
+  auto sol_z = [&](int k) -> double { if constexpr (sizeof(TQ) == 4) return D[L.zd + k]; else return (double)S[L.z + k]; };
   int unsound = 0;
-  for (int it = tid; it < (N + 1) * VS; it += 64) { const TQ v = S[L.dx + it]; if (!(tabs(v) < TQ(1e30))) unsound = 1; }
-  for (int i = tid; i < nv; i += 64) { const TQ v = S[L.z + i]; if (!(tabs(v) < TQ(1e30))) unsound = 1; }
+  for (int it = tid; it < (N + 1) * VS; it += 64) { const double v = sol_dx(it); if (!(fabs(v) < 1e30)) unsound = 1; }
+  for (int i = tid; i < nv; i += 64) { const double v = sol_z(i); if (!(fabs(v) < 1e30)) unsound = 1; }
   unsound = wave_max(unsound);
   if (unsound) status = 1;
   else {
     for (int it = tid; it < (N + 1) * NX; it += 64) {
       const int i = it / NX, k = it - i * NX;
-      const double v = D[L.X + it] + (double)S[L.dx + i * VS + o2i(k)];
+      const double v = D[L.X + it] + sol_dx(i * VS + o2i(k));
       D[L.X + it] = v; gX[it] = v;
     }
     for (int i = tid; i < nv; i += 64) {
-      double v = D[L.U + i] + (double)S[L.z + i];
+      double v = D[L.U + i] + sol_z(i);
       v = tmin(tmax(v, m.ulb[i & 3]), m.uub[i & 3]);   // the QP keeps du inside [lb, ub]; removes the rounding of TQ -> double
       D[L.U + i] = v; gU[i] = v;
     }
@@ -2455,9 +2768,6 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   cst = wave_sum(cst);
   bad = wave_max(bad);
   if (bad) status = 1;
-  // TQ = float: a step whose QP went through the interior-point fallback is outside the 1e-4 control budget of the fast mode
-  // (include/mpcq.h, MPCQ_SOLVE_LOW_ACCURACY): taken, but reported
-  if (sizeof(TQ) == 4 && status == 0 && ((iters / 1000) % 10 != 0 || prev_iter == 0)) status = 8;   // fallback solve or cold start
   if (tid == 0) { st.cost[b] = cst; st.status[b] = status; st.qp_iter[b] = iters; st.qp_work[b] = work; }
 #ifdef MPCQ_TRACE_NAN
   trace(3, (unsigned long long)(status & 0xff) | (unsigned long long)unsound << 8 | (unsigned long long)bad << 9 | (unsigned long long)(unsigned)prev_iter << 32);
@@ -2562,7 +2872,7 @@ __global__ void predict_kernel(const DevModel<TQ> m, const double* x, const doub
 
 template <typename TQ>
 __global__ void regress_kernel(const DevModel<TQ> m, const DevState<TQ> st, const double* vb, const double* ad) {
-  const Lds L = lds_layout(m.N, m.nb, m.gab);
+  const Lds L = lds_layout(m.N, m.nb, m.gab, sizeof(TQ) == 4);
 #ifdef MPCQ_CHECKED
   if (threadIdx.x == 0) *reinterpret_cast<int**>(smem_raw) = st.chk;
   __syncthreads();

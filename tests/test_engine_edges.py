@@ -203,11 +203,8 @@ def _free_running_equals_lockstep(lib):
             mu, C = e.get_rgp()
             res.append([*e.sim_get_state(), st["X"], st["U"], st["idx"], mu, C, e.get_tracking_stats(), e.get_status(), e.get_cost()])
             e.close()
-        if precision == 0 or lib is not None:
-            for a, b in zip(*res):
-                assert np.array_equal(np.asarray(a), np.asarray(b))
-        else:   # fp32 on the GPU: specialised lockstep instance vs any-shape free-running instance, equal to rounding (see test_gpu_parity)
-            assert np.array_equal(res[0][4], res[1][4]) and np.allclose(res[0][7][:3], res[1][7][:3], rtol=0.1, atol=1e-6)
+        for a, b in zip(*res):      # bit for bit in both precisions (both launch modes run the shape-specialised instance of the precision)
+            assert np.array_equal(np.asarray(a), np.asarray(b))
         assert (res[0][4] == K + 2).all()
 
 
