@@ -425,6 +425,9 @@ def main():
                     help="quadrotors per GPU; default 1024 (BASELINE configs[1]) at EVERY world size: the `value` series over N GPUs is a "
                          "weak-scaling series.  configs[3] (8192 per GPU, 65 536 over 8) rides in every line as the `swarm` leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations (and the swarm leg)")
+    ap.add_argument("--swarm-per-rank", type=int, default=0,
+                    help=f"quadrotors per GPU of the configs[3] `swarm` leg (default {SWARM_PER_RANK} = 65 536 / 8; a smaller value is a testing aid and "
+                         "switches the leg on for any --batch)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity check on the workload")
     ap.add_argument("--steady", type=int, default=200, help="control periods of the steady-state leg that follows the timed region on the same engine "
                                                             "(one GPU only; 0: skip it and the other-seeds legs)")
@@ -465,13 +468,14 @@ def main():
     periods = args.preroll + args.warmup + args.steps + STEADY + LAT
     headline = (B, N, nb) == (1024, 20, 10)
     legs = world == 1 and not args.no_configs and headline
-    swarm = not args.no_configs and headline           # configs[3]: 8192 quadrotors on every rank, at every world size
+    swarm = not args.no_configs and (headline or args.swarm_per_rank > 0)   # configs[3]: 8192 quadrotors on every rank, at every world size
+    SWARM = args.swarm_per_rank if args.swarm_per_rank > 0 else SWARM_PER_RANK
     seeds_alt = [1, 2, 3] if (world == 1 and headline and STEADY > 0) else []
     t_gen = time.perf_counter()
     refs = workload(args.seed, rank * B, B, periods)      # host-side generation (worker processes) before the GPU is touched
     CFG_PRE, CFG_WARM, CFG_STEPS = 300, 5, 20
     refs_cfg = workload(args.seed, 0, 8192, CFG_PRE + CFG_WARM + CFG_STEPS) if legs else None   # shared by the legs (150 rows >= N skip)
-    refs_swarm = workload(args.seed, rank * SWARM_PER_RANK, SWARM_PER_RANK, args.preroll + SWARM_WARM + SWARM_STEPS) if swarm else None
+    refs_swarm = workload(args.seed, rank * SWARM, SWARM, args.preroll + SWARM_WARM + SWARM_STEPS) if swarm else None
     refs_seeds = {sd: workload(sd, 0, B, args.preroll + 10 + 50) for sd in seeds_alt}
     t_gen = time.perf_counter() - t_gen
     e, cfg = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods, refs=refs)
@@ -540,7 +544,7 @@ def main():
     # ---- configs[3]-shaped leg on every rank: 8192 quadrotors per GPU (65 536 over 8), same pre-roll as the headline
     swarm_out = None
     if swarm:
-        leg, es, agg_dt = config_leg(f"configs[3] per rank: batch {SWARM_PER_RANK} of {SWARM_PER_RANK * 8}, N=20, RGP 10 basis pts", refs_swarm, SWARM_PER_RANK, 20, 10,
+        leg, es, agg_dt = config_leg(f"configs[3] per rank: batch {SWARM} of {SWARM * 8}, N=20, RGP 10 basis pts", refs_swarm, SWARM, 20, 10,
                                      PRECISION_F64, local_rank, args.preroll, SWARM_WARM, SWARM_STEPS, dist=dist, keep=True)
         if dist is not None:      # between the barriers, MAX over ranks (as the headline)
             import torch
@@ -548,15 +552,29 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             agg_dt = float(t[0])
         sranks = per_rank_summary(dist, world, {"ms_per_step": leg["ms_per_step"], "kernel_avg_ms": leg["kernel_avg_ms"], "steps_per_s": leg["value"]})
-        # (the statistic of this leg goes over the host group under WORLD_SIZE > 1: the RCCL reduction of the path is the headline's, one
-        #  communicator per process; a second one here would only add a way for the line to fail)
-        sstats, show, _ = reduce_stats(es, dist, world, False)
+        # configs[3] IS "RCCL reduce of tracking RMSE": this engine reduces its own statistic over the rank's communicator (the one the
+        # headline engine initialised: one communicator per rank, mpcq_comm_share)
+        swarm_rccl = world > 1 and stats_reduce == "rccl"
+        if swarm_rccl:
+            try:
+                es.comm_share(e)
+            except Exception as ex:      # noqa: BLE001
+                print(f"# rank {rank}: mpcq_comm_share failed: {ex}", file=sys.stderr)
+                swarm_rccl = False
+            import torch
+            flag = torch.tensor([1 if swarm_rccl else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            swarm_rccl = int(flag[0]) == 1
+        sstats, show, hung3 = reduce_stats(es, dist, world, swarm_rccl)
+        rccl_hung = rccl_hung or hung3
+        if world > 1 and stats_reduce == "rccl" and show != "rccl":
+            stats_reduce = "rccl (headline), " + show + " (swarm)"      # strict mode: the run fails, the line says which reduction did not run
         es.close()
         best = sranks["steps_per_s"]["max"]
         swarm_out = dict(leg)
         # HBM roofline of this leg (per GPU): algorithmic bytes over the launch time by HIP events; memory-side traffic from the rocprofv3 passes of this
         # configuration, attached only when they were taken on this build (source hash)
-        sw_bytes = algorithmic_bytes(20, 10, 8) * SWARM_PER_RANK
+        sw_bytes = algorithmic_bytes(20, 10, 8) * SWARM
         sw_roof = {"bound": "hbm", "achieved": sw_bytes / (leg["kernel_avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                    "algorithmic_bytes_per_launch": sw_bytes}
         sw_roof["frac"] = sw_roof["achieved"] / HBM_PEAK_GBS
@@ -570,10 +588,10 @@ def main():
         except (OSError, ValueError):
             pass
         swarm_out["roofline"] = sw_roof
-        swarm_out.update({"config": f"BASELINE configs[3]: swarm of {SWARM_PER_RANK * world} quadrotors, {SWARM_PER_RANK} per GPU over {world} GPU(s)"
+        swarm_out.update({"config": f"BASELINE configs[3]: swarm of {SWARM * world} quadrotors, {SWARM} per GPU over {world} GPU(s)"
                                     + (" (= the per-rank shard of the 65 536-quadrotor swarm)" if world == 1 else ""),
-                          "value": SWARM_PER_RANK * world * SWARM_STEPS / agg_dt, "n_gpus": world, "global_batch": SWARM_PER_RANK * world,
-                          "ms_per_step": 1e3 * agg_dt / SWARM_STEPS, "per_rank": sranks, "efficiency_vs_best_rank": SWARM_PER_RANK * world * SWARM_STEPS / agg_dt / (world * best),
+                          "value": SWARM * world * SWARM_STEPS / agg_dt, "n_gpus": world, "global_batch": SWARM * world,
+                          "ms_per_step": 1e3 * agg_dt / SWARM_STEPS, "per_rank": sranks, "efficiency_vs_best_rank": SWARM * world * SWARM_STEPS / agg_dt / (world * best),
                           "stats_reduce": show, "rms_pos_m": float(np.sqrt(sstats[0] / (3 * max(sstats[2], 1)))), "tracking_steps": float(sstats[2])})
 
     if rank == 0:
@@ -619,6 +637,10 @@ def main():
         }
         if steady is not None:
             out["steady_state"] = steady
+            # machine-readable form of "which number is representative": `value` is the driver's short window, whose launches hold more or
+            # fewer saturated quadrotors by chance; the steady-state leg is the figure to quote
+            out["value_window"] = {"steps": args.steps, "ms": 1e3 * elapsed, "representative": "steady_state.value",
+                                   "value_over_steady_state": value / steady["value"]}
         if lat is not None:
             out["latency_roofline"] = lat
         if swarm_out is not None:
@@ -704,8 +726,8 @@ def main():
                 config_leg("configs[2]: batch 8192, N=20, RGP 20 basis pts", refs_cfg, 8192, 20, 20, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
                 config_leg("configs[2]: batch 8192, N=20, RGP 20 basis pts", refs_cfg, 8192, 20, 20, PRECISION_F32, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS, parity=par),
                 {k: v for k, v in swarm_out.items() if k not in ("per_rank", "efficiency_vs_best_rank", "n_gpus", "global_batch", "stats_reduce", "tracking_steps", "roofline")}
-                | {"config": f"configs[3] per rank: batch {SWARM_PER_RANK} of {SWARM_PER_RANK * 8}, N=20, RGP 10 basis pts (the `swarm` leg of this line: same pre-roll as an N > 1 run)"},
-                config_leg(f"configs[3] per rank: batch {SWARM_PER_RANK} of {SWARM_PER_RANK * 8}, N=20, RGP 10 basis pts", refs_swarm, SWARM_PER_RANK, 20, 10, PRECISION_F32, local_rank,
+                | {"config": f"configs[3] per rank: batch {SWARM} of {SWARM * 8}, N=20, RGP 10 basis pts (the `swarm` leg of this line: same pre-roll as an N > 1 run)"},
+                config_leg(f"configs[3] per rank: batch {SWARM} of {SWARM * 8}, N=20, RGP 10 basis pts", refs_swarm, SWARM, 20, 10, PRECISION_F32, local_rank,
                            args.preroll, SWARM_WARM, SWARM_STEPS, parity=par),
                 config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F64, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS),
                 config_leg("configs[4]: batch 4096, N=50, RGP 50 basis pts", refs_cfg, 4096, 50, 50, PRECISION_F32, local_rank, CFG_PRE, CFG_WARM, CFG_STEPS, parity=par),

@@ -129,11 +129,18 @@ const char* mpcq_version(void);
 
 /* ---- lifetime.  quad_optimizer.__init__ (src/quad_opt.py:36-160): builds constants, K_x^-1,
  * allocates device state and zero-initialises the iterate (acados default), mu=0, C=K_x. */
-int mpcq_create(const mpcq_config* cfg, mpcq_engine** out);     /* cfg has THIS header's layout (== mpcq_create_sized(cfg, sizeof(mpcq_config), out)) */
 /* Versioned form: cfg_size = the caller's sizeof(mpcq_config).  Fields behind cfg_size take their defaults (0), so a
  * caller built against an older header keeps working; sizes that end before `device` or exceed this library's struct
  * are refused. */
 int mpcq_create_sized(const mpcq_config* cfg, uint64_t cfg_size, mpcq_engine** out);
+/* mpcq_create(cfg, out): for source callers an inline that passes THIS header's sizeof(mpcq_config); the exported symbol of the
+ * same name exists for binaries built against the 0.3 header only and reads the 0.3 layout (the struct has grown since: a library
+ * that copied its own sizeof would read behind such a caller's struct). */
+#ifdef MPCQ_BUILDING_LIBRARY
+int mpcq_create(const mpcq_config* cfg, mpcq_engine** out);
+#else
+static inline int mpcq_create(const mpcq_config* cfg, mpcq_engine** out) { return mpcq_create_sized(cfg, sizeof(mpcq_config), out); }
+#endif
 int mpcq_destroy(mpcq_engine* e);
 int mpcq_reset(mpcq_engine* e);
 
@@ -254,6 +261,11 @@ int mpcq_get_tracking_stats(mpcq_engine* e, double out[5]);
  * vector (RCCL over xGMI).  The host exchanges the 128-byte unique id however it likes. */
 int mpcq_comm_unique_id(void* id128);
 int mpcq_comm_init(mpcq_engine* e, int32_t rank, int32_t nranks, const void* id128);
+/* A second engine of the same process and device reduces over the communicator `owner` initialised (since 0.5): one rank = one
+ * communicator however many engines it runs (bench.py: the configs[3] swarm next to the configs[1] headline).  `e` borrows the
+ * handle, `owner` has to outlive it (or `e` must not reduce any more); calls on the two engines must not overlap in time.
+ * The RCCL library is dlopen'ed by name (librccl.so, then /opt/rocm/lib/librccl.so); MPCQ_RCCL_LIB in the environment names another file. */
+int mpcq_comm_share(mpcq_engine* e, mpcq_engine* owner);
 /* sum (out[0..2], out[4]) / max (out[3]) over ranks; every rank receives the result */
 int mpcq_allreduce_tracking_stats(mpcq_engine* e, double out[5]);
 

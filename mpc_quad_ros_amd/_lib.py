@@ -57,6 +57,7 @@ SYMBOLS = [
     ("mpcq_get_tracking_stats", ctypes.c_int, [_vp, _dp]),
     ("mpcq_comm_unique_id", ctypes.c_int, [_vp]),
     ("mpcq_comm_init", ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp]),
+    ("mpcq_comm_share", ctypes.c_int, [_vp, _vp]),
     ("mpcq_allreduce_tracking_stats", ctypes.c_int, [_vp, _dp]),
     ("mpcq_get_state", ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),
     ("mpcq_set_state", ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]),

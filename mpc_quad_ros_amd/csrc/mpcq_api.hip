@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#define MPCQ_BUILDING_LIBRARY
 #include "../../include/mpcq.h"
 #include "mpcq_kernels.hpp"
 
@@ -90,7 +91,12 @@ struct Rccl {
 Rccl g_rccl;
 int rccl_load() {
   if (g_rccl.lib) return 0;
-  void* l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  void* l = nullptr;
+  if (const char* named = getenv("MPCQ_RCCL_LIB")) {   // another file than the system's RCCL (tests: a stand-in that reduces over shared memory)
+    l = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
+    if (!l) return fail(MPCQ_ERR_COMM, std::string("dlopen MPCQ_RCCL_LIB: ") + dlerror());
+  }
+  if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!l) l = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!l) return fail(MPCQ_ERR_COMM, std::string("dlopen librccl.so: ") + dlerror());
   g_rccl.GetUniqueId = (int (*)(void*))dlsym(l, "ncclGetUniqueId");
@@ -163,6 +169,7 @@ struct mpcq_engine {
   bool have_traj = false, timed = false;
   bool tuning_env = false;   // MPCQ_TUNING=1: measurement scripts may override tuning fields through the environment
   void* comm = nullptr;
+  bool comm_borrowed = false;   // comm belongs to another engine of this process (mpcq_comm_share)
   int nranks = 1;
   double* d_stats5 = nullptr;
   std::vector<hipEvent_t> kev;   // per-launch event pairs of the last sim_steps call
@@ -235,7 +242,7 @@ struct EngineT : mpcq_engine {
     if (ev1) (void)hipEventDestroy(ev1);
     for (hipEvent_t ev : kev) (void)hipEventDestroy(ev);
     if (stream) (void)hipStreamDestroy(stream);
-    if (comm && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
+    if (comm && !comm_borrowed && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
   }
 
   template <typename P> int dalloc(P*& p, size_t n) {
@@ -287,7 +294,7 @@ struct EngineT : mpcq_engine {
     const bool env = tuning_env = getenv("MPCQ_TUNING") && atoi(getenv("MPCQ_TUNING")) != 0;
     if (!env) {   // advisor finding: a measurement script that forgets MPCQ_TUNING=1 would otherwise compare identical configurations
       static const char* const knobs[] = {"MPCQ_WARM_MAX", "MPCQ_WARM_RETRY", "MPCQ_FLIP_MAX", "MPCQ_ABORT_PINS", "MPCQ_ABORT_WRONG", "MPCQ_POLISH_MAX", "MPCQ_PIN_RATIO",
-                                          "MPCQ_IPM_MU0", "MPCQ_IPM_MARGIN", "MPCQ_IPM_TOL", "MPCQ_STAGE_MEM", "MPCQ_GENERIC", "MPCQ_BLOCK_ORDER", "MPCQ_KEV_STRIDE"};
+                                          "MPCQ_IPM_MU0", "MPCQ_IPM_MARGIN", "MPCQ_IPM_TOL", "MPCQ_STAGE_MEM", "MPCQ_GENERIC", "MPCQ_BLOCK_ORDER", "MPCQ_KEV_STRIDE", "MPCQ_SPLIT_PLANT"};
       static bool warned = false;
       for (const char* k : knobs)
         if (!warned && getenv(k)) { fprintf(stderr, "mpcq: %s is set but MPCQ_TUNING=1 is not: the environment is ignored (use mpcq_config.tune)\n", k); warned = true; }
@@ -452,7 +459,13 @@ struct EngineT : mpcq_engine {
       const size_t resident = occ[layout] * (size_t)n_cu;
       const int bo = ienv("MPCQ_BLOCK_ORDER", tu.block_order);
       use_order = bo == 2 || (bo == 0 && (size_t)B > resident);
-      if (use_order && (rc = dalloc(d_order, Bz))) return rc;
+      if (use_order) {   // the identity until the first lockstep launch has computed an order (mpcq_get_block_order before that)
+        if ((rc = dalloc(d_order, Bz))) return rc;
+        std::vector<int> ident(Bz);
+        for (size_t b = 0; b < Bz; ++b) ident[b] = (int)b;
+        HIP_TRY(hipMemcpyAsync(d_order, ident.data(), Bz * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+      }
       // The same distinction decides where the plant update of the on-device closed loop runs (sim_steps): at the head of the next
       // step launch (one launch per period; its RK4 substeps run on one lane of every workgroup: 6 k of a quadrotor's 172 k cycles)
       // or as its own launch of one THREAD per quadrotor.  A resident batch waits for its slowest quadrotor, which the 2.5 us at
@@ -540,14 +553,18 @@ struct EngineT : mpcq_engine {
     return 0;
   }
   int base_mode() const { return (cfg.flags & MPCQ_FLAG_STATIC_GP) ? mpcq::MODE_STATIC_GP : 0; }
-  void launch_period(const mpcq::DevState<T>& s, int mode) {
-    if (use_order) {   // (reads qp_iter of the previous period; a permutation by construction whatever qp_iter holds)
+  // one lockstep period; ev_begin (if any) is recorded in front of the STEP kernel, behind the ordering launch, so that the event
+  // pairs of sim_steps time the step kernel alone
+  void launch_period(const mpcq::DevState<T>& s, int mode, hipEvent_t ev_begin = nullptr) {
+    if (use_order) {   // (reads qp_iter of the previous period; a permutation by construction whatever qp_iter holds: order_bin is total)
       hipLaunchKernelGGL(mpcq::order_kernel, dim3(mpcq::ORD_CLASSES), dim3(mpcq::ORD_THREADS), mpcq::ORD_LDS, stream, (const int*)st.qp_iter, B, d_order);
       mpcq::DevState<T> so = s;
       so.order = d_order;
+      if (ev_begin) (void)hipEventRecord(ev_begin, stream);
       hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, so, mode);
       return;
     }
+    if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode);
   }
   int launch_step(int mode) {
@@ -663,8 +680,7 @@ struct EngineT : mpcq_engine {
     for (int k = 0; k < K; ++k) {
       const bool timed_launch = k % stride == 0;
       const int mode = mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode() | ((!split && k > 0) ? mpcq::MODE_PLANT_FIRST : 0);
-      if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride)], stream));
-      launch_period(s2, mode);
+      launch_period(s2, mode, timed_launch ? kev[2 * (k / stride)] : nullptr);
       if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride) + 1], stream));
       if (split || k == K - 1)
         hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, stream, m, d_xs, st.w, n_sub, sim_dt, B);
@@ -840,12 +856,14 @@ const char* mpcq_last_error(void) { return g_err.c_str(); }
 #define MPCQ_SRC_ID "unknown"
 #endif
 #ifdef MPCQ_CHECKED
-const char* mpcq_version(void) { return "mpcq 0.4 (gfx950, CHECKED diagnostic build, source " MPCQ_SRC_ID ")"; }
+const char* mpcq_version(void) { return "mpcq 0.5 (gfx950, CHECKED diagnostic build, source " MPCQ_SRC_ID ")"; }
 #else
-const char* mpcq_version(void) { return "mpcq 0.4 (gfx950, source " MPCQ_SRC_ID ")"; }
+const char* mpcq_version(void) { return "mpcq 0.5 (gfx950, source " MPCQ_SRC_ID ")"; }
 #endif
 
-int mpcq_create(const mpcq_config* c, mpcq_engine** out) { return mpcq_create_sized(c, sizeof(mpcq_config), out); }
+// binaries built against the 0.3 header (source callers get the header's inline, which passes their own sizeof): the 0.3 layout ends
+// in front of mpcq_tuning.block_order
+int mpcq_create(const mpcq_config* c, mpcq_engine** out) { return mpcq_create_sized(c, offsetof(mpcq_config, tune) + offsetof(mpcq_tuning, block_order), out); }
 int mpcq_create_sized(const mpcq_config* c_in, uint64_t cfg_size, mpcq_engine** out) {
   if (!c_in || !out) return fail(MPCQ_ERR_INVALID, "null argument");
   *out = nullptr;
@@ -990,6 +1008,17 @@ int mpcq_comm_init(mpcq_engine* e, int32_t rank, int32_t nranks, const void* id1
   const int r = g_rccl.CommInitRank(&e->comm, nranks, id, rank);
   if (r) { e->comm = nullptr; return fail(MPCQ_ERR_COMM, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); }
   e->nranks = nranks;
+  return 0;
+}
+int mpcq_comm_share(mpcq_engine* e, mpcq_engine* owner) {
+  ENTER(e);
+  if (!owner || owner == e) return fail(MPCQ_ERR_INVALID, "mpcq_comm_share: bad owner");
+  if (e->comm) return fail(MPCQ_ERR_STATE, "communicator already initialised");
+  if (!owner->comm || owner->comm_borrowed) return fail(MPCQ_ERR_STATE, "mpcq_comm_share: the owner has no communicator of its own");
+  if (owner->cfg.device != e->cfg.device) return fail(MPCQ_ERR_INVALID, "mpcq_comm_share: the two engines live on different devices");
+  e->comm = owner->comm;
+  e->comm_borrowed = true;
+  e->nranks = owner->nranks;
   return 0;
 }
 int mpcq_allreduce_tracking_stats(mpcq_engine* e, double out[5]) {

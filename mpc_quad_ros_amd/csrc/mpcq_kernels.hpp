@@ -2960,6 +2960,7 @@ static __global__ void stats_kernel(const double* stats, const int* status, int 
 constexpr int ORD_BINS = 16, ORD_THREADS = 256, ORD_CLASSES = 8;
 constexpr size_t ORD_LDS = (size_t)(ORD_BINS * ORD_THREADS + ORD_BINS) * sizeof(int);
 __host__ __device__ inline int order_bin(int q) {   // bin 0 = most expensive
+  if (q < 0) q = 0;   // (not a value the solver writes; whatever a restored checkpoint holds, the result is a bin)
   const int total = q % 1000, marked = (q / 1000) % 100 != 0;   // fallback solve (x 1000) or flip mark (x 10000)
   int cost = q == 0 ? ORD_BINS - 1 : (total < ORD_BINS - 1 ? total : ORD_BINS - 1);   // cold start: interior point from scratch
   if (marked && cost < 8) cost = 8;

@@ -33,7 +33,7 @@ def qp_warm_exit(it):
 
 def order_bin(it):
     """Cost bin of mpcq::order_kernel (0 = predicted most expensive) for a qp_iter value of the previous period."""
-    it = np.asarray(it)
+    it = np.maximum(np.asarray(it), 0)      # (a negative value is not one the solver writes: binned like a cold start, as on the device)
     total = it % 1000
     cost = np.where(it == 0, 15, np.minimum(total, 15))
     cost = np.where(((it // 1000) % 100 != 0) & (cost < 8), 8, cost)
@@ -276,6 +276,10 @@ class Engine:
     def comm_init(self, rank, nranks, uid: bytes):
         buf = ctypes.create_string_buffer(uid, 128)
         self._check(self.lib.mpcq_comm_init(self.h, rank, nranks, buf))
+
+    def comm_share(self, owner: "Engine"):
+        """Reduce over the communicator another engine of this process initialised (one communicator per rank)."""
+        self._check(self.lib.mpcq_comm_share(self.h, owner.h))
 
     def allreduce_tracking_stats(self):
         out = np.zeros(5)

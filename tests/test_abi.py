@@ -58,7 +58,7 @@ def test_code_objects_pass_the_exec_prologue_check():
     chk = os.path.join(ROOT, "tools", "check_exec_prologue.py")
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("no ROCm LLVM tools on this runner")
-    bad = subprocess.run([sys.executable, chk, os.path.join(ROOT, "tools", "repro_codegen", "isa_excerpt_BB10_117.s")], capture_output=True, text=True)
+    bad = subprocess.run([sys.executable, chk, "--min-instructions=1", os.path.join(ROOT, "tools", "repro_codegen", "isa_excerpt_BB10_117.s")], capture_output=True, text=True)
     assert bad.returncode == 1 and "EXEC = 0" in bad.stdout and "v_accvgpr_write_b32" in bad.stdout, bad.stdout
     # the same misplacement behind an SGPR spill to scratch (-amdgpu-spill-sgpr-to-vgpr=0: EXEC saved, set to a constant, restored) and a
     # legitimate join (per-lane copy at the end of a divergent `if`, nothing but the EXEC restore behind a loop exit)
@@ -71,10 +71,20 @@ def test_code_objects_pass_the_exec_prologue_check():
         open(ok2, "w").write("_ZN4mpcq11step_kernel_synthetic_okEv:\n.LBB1_1:\n\ts_andn2_b64 exec, exec, s[18:19]\n\ts_cbranch_execnz .LBB1_1\n.LBB1_2:\n"
                              "\tv_writelane_b32 v9, s34, 0\n\ts_or_b64 exec, exec, s[2:3]\n\tv_accvgpr_write_b32 a1, v7\n\ts_cbranch_execz .LBB1_4\n.LBB1_3:\n\tv_mov_b32_e32 v3, v4\n.LBB1_4:\n"
                              "\tv_mov_b32_e32 v5, v3\n\ts_or_b64 exec, exec, s[6:7]\n\ts_endpgm\n.Lfunc_end1:\n")
-        r_bad = subprocess.run([sys.executable, chk, bad2], capture_output=True, text=True)
-        r_ok = subprocess.run([sys.executable, chk, ok2], capture_output=True, text=True)
+        r_bad = subprocess.run([sys.executable, chk, "--min-instructions=1", bad2], capture_output=True, text=True)
+        r_ok = subprocess.run([sys.executable, chk, "--min-instructions=1", ok2], capture_output=True, text=True)
         assert r_bad.returncode == 1 and "v_accvgpr_write_b32 a1, v7" in r_bad.stdout, r_bad.stdout
         assert r_ok.returncode == 0, r_ok.stdout
+        # the gate fails CLOSED (advisor finding of round 4): an input in which nothing could be verified -- an assembly file without a
+        # kernel, a kernel of a handful of parsed lines, a host-only object, a missing file -- is exit status 2, not "clean"
+        empty, host = os.path.join(tmp, "empty.s"), os.path.join(tmp, "host.o")
+        open(empty, "w").write("\t.text\n")
+        assert subprocess.run([sys.executable, chk, empty], capture_output=True, text=True).returncode == 2
+        assert subprocess.run([sys.executable, chk, ok2], capture_output=True, text=True).returncode == 2            # 8 lines: below the default minimum
+        assert subprocess.run([sys.executable, chk, os.path.join(tmp, "missing.o")], capture_output=True, text=True).returncode == 2
+        src = os.path.join(tmp, "host.c"); open(src, "w").write("int f(int a) { return a + 1; }\n")
+        if subprocess.run(["gcc", "-c", "-o", host, src]).returncode == 0:
+            assert subprocess.run([sys.executable, chk, host], capture_output=True, text=True).returncode == 2
     # disassembly has no labels: a join that no branch targets is merged with the `if` body in front of it.  The body's own reload
     # (consumed inside the body) must pass, spill code directly in front of the restore must not
     import importlib.util
@@ -87,7 +97,9 @@ def test_code_objects_pass_the_exec_prologue_check():
     assert mod.check(late, labelled=False) != []
     good = subprocess.run([sys.executable, chk, _lib.DEFAULT_LIB], capture_output=True, text=True)
     assert good.returncode == 0, good.stdout[-2000:]
-    assert good.stdout.count("clean") >= 20          # every step-kernel instance of the library was looked at
+    # every step-kernel instance of the library was looked at, and really parsed: tens of thousands of instruction lines each
+    lines = [int(n) for n in re.findall(r"step_kernel<.*?: clean \((\d+) lines\)", good.stdout)]
+    assert len(lines) >= 20 and min(lines) > 5000, (len(lines), min(lines) if lines else None)
 
 
 def test_no_gpu_fails_loudly():

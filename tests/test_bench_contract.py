@@ -12,9 +12,13 @@ REQ = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "h
        "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
 @pytest.fixture(scope="module", autouse=True)
 def build_emu():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "wave_emu")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "fake_rccl")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def _check(line, n):
@@ -80,3 +84,33 @@ def test_two_ranks_strict_rccl_is_the_default():
     assert r.returncode != 0
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["config"]["rccl_ok"] is False      # the line is still printed, and says which reduction ran
+
+
+def test_eight_ranks_reduce_both_statistics_through_the_rccl_branch():
+    """Dry run of the driver's 8-GPU launch (python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8): eight ranks on the
+    lane emulator, with the RCCL branch of libmpcq ACTIVE -- MPCQ_RCCL_LIB points the library at a test-only stand-in that reduces over
+    shared memory (tests/fake_rccl) -- and strict mode on (the default): unique id from rank 0, one communicator per rank, the configs[1]
+    headline reduced through it, the configs[3] swarm leg (its own engine, here 2 quadrotors per rank) reduced through the SAME
+    communicator (mpcq_comm_share), both statistics complete, the line self-consistent over 8 ranks."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "run_bench_emu.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--preroll", "2",
+           "--batch", "1", "--horizon", "5", "--nb", "0", "--swarm-per-rank", "2"]
+    env = dict(os.environ, MPCQ_RCCL_LIB=FAKE_RCCL, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]           # strict mode: a reduction that fell back to the host group would exit non-zero
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-3000:]
+    d = _check(lines[0], 8)
+    assert d["config"]["global_batch"] == 8 and d["config"]["batch_per_gpu"] == 1 and d["config"]["parallelism"] == "shard8"
+    assert d["config"]["stats_reduce"] == "rccl" and d["config"]["rccl_ok"] is True
+    pr = d["per_rank"]
+    assert len(pr["ranks"]) == 8
+    assert abs(d["efficiency_vs_best_rank"] - d["value"] / (8 * pr["steps_per_s"]["max"])) < 1e-12 and 0 < d["efficiency_vs_best_rank"] <= 1.0 + 1e-9
+    # the swarm leg: 2 quadrotors on each of 8 ranks, its statistic over the same communicator
+    sw = d["swarm"]
+    assert sw["n_gpus"] == 8 and sw["global_batch"] == 16 and sw["stats_reduce"] == "rccl"
+    assert len(sw["per_rank"]["ranks"]) == 8 and 0 < sw["efficiency_vs_best_rank"] <= 1.0 + 1e-9
+    assert sw["tracking_steps"] == 16 * (2 + 5 + 20)              # every rank's (pre-roll + warm-up + timed) periods arrived in the sum
+    assert d["tracking"]["steps"] == 8 * (2 + 1 + 2)

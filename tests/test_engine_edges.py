@@ -150,7 +150,7 @@ def _versioned_create(lib_path):
     for size in (CConfig.device.offset, ctypes.sizeof(CConfig) + 8):
         assert lib.mpcq_create_sized(ctypes.cast(raw, ctypes.c_void_p), size, ctypes.byref(h)) != 0
         assert b"size" in lib.mpcq_last_error()
-    assert b"0.4" in lib.mpcq_version()
+    assert b"0.5" in lib.mpcq_version()
 
 
 def _reference_format_log(lib):
@@ -180,6 +180,42 @@ def _reference_format_log(lib):
     t_cpu = np.array([q["t_cpu"][k, 0] for k in range(4)])
     assert np.isclose(avg, np.mean(t_cpu)) and np.isclose(std, np.std(t_cpu)) and np.isclose(per_quad, avg / B) and avg >= 0
     assert lg.summary_title().startswith("MPC CPU Time, Avg: ")
+
+
+def _reference_analysis_round_trip(lib):
+    """f2 round trip: a run of the engine on the REFERENCE's own measurements (a logged python-sim flight: x_odom fed step by step,
+    x_ref = row 0 of every chunk, as the node logs it, src/execute_trajectory.py:270-273) is written by SwarmLogger.save() as a pickle
+    in the reference's layout and read back by a restatement of Visualiser.plot_data's numeric path (tests/helpers.visualiser_summaries:
+    src/Visualiser.py:787-811,918,981-987).  The total position RMS it prints equals (i) the statistic the device accumulates
+    (mpcq_get_tracking_stats, a10) and (ii) the same analysis run on the reference's golden log itself; the CPU-time panel equals the
+    logger's own summary."""
+    import tempfile
+    from mpc_quad_ros_amd.logger import SwarmLogger
+    from helpers import config_for_log, load_golden, visualiser_summaries
+    g = load_golden("log_traj0_v10_a10_gp2.npz")
+    K = 12 if lib is not None else 100
+    e = Engine(config_for_log(g), lib_path=lib)
+    e.set_trajectories(g["x_ref"][None])
+    lg = SwarmLogger(e)
+    for k in range(K):
+        x = g["x_odom"][k][None]
+        chunk0 = e.get_reference_chunk()[:, 0]            # row 0 of this step's chunk (get_reference_chunk at the current cursor)
+        assert np.array_equal(chunk0[0], g["x_ref"][k])   # = what the reference logged as x_ref
+        w, xp = e.step(x)
+        lg.log_step(0.1 * k, x, w, xp, chunk0)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "run.pkl")
+        lg.save(path, 0)
+        mine = visualiser_summaries(path)
+    ref = visualiser_summaries({"x_odom": g["x_odom"][:K], "x_ref": g["x_ref"][:K], "t_cpu": np.zeros((K, 1))})
+    st = e.get_tracking_stats()
+    assert st[2] == K
+    assert np.isclose(mine["rms_total"], np.sqrt(st[0] / (3 * st[2])), rtol=1e-12, atol=0)          # the device's accumulators
+    assert mine["rms_total"] == ref["rms_total"] and np.array_equal(mine["rms_pos_ref"], ref["rms_pos_ref"])   # the reference's own log
+    assert np.isclose(np.sqrt(st[3]), np.sqrt(3.0) * mine["rms_pos_ref"].max(), rtol=1e-12)          # max |e_pos| = sqrt(3) x the largest per-step RMS
+    avg, std, _ = lg.cpu_time_summary()
+    assert mine["avg_cpu"] == avg and mine["std_cpu"] == std and mine["title_cpu"] == lg.summary_title()
+    assert mine["title_rms"].startswith("RMS Position Error, Total: ") and mine["title_rms"].endswith("mm")
 
 
 def _free_running_equals_lockstep(lib):
@@ -386,7 +422,7 @@ def _static_gp_model_path(lib):
     assert not np.array_equal(e2.get_rgp()[0].reshape(B, -1), mu)
 
 
-CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log, _free_running_equals_lockstep,
+CASES = [_ragged_and_exhausted, _reset_and_state_roundtrip, _argument_errors, _reference_format_log, _reference_analysis_round_trip, _free_running_equals_lockstep,
          _command_and_finished, _chunk_cases_on_device, _plant_period_matches_reference_logs, _checkpoint_resume_is_bitwise,
          _rgp_learn_matches_reference_streams, _static_gp_model_path, _work_counters]
 

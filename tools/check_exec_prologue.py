@@ -181,25 +181,60 @@ def check(ins, labelled=True):
     return findings
 
 
+MIN_INSTRUCTIONS = 50      # a kernel of this library disassembles to tens of thousands of lines; a handful means the parse failed
+
+
 def main(paths):
+    """Exit status: 0 every kernel parsed and clean | 1 the pattern was found | 2 NOTHING COULD BE VERIFIED for some input (no gfx950
+    code object, no kernel symbol, or a kernel with fewer than MIN_INSTRUCTIONS parsed lines: a changed disassembly format, another
+    ARCH, a host-only object) -- the gate fails closed.  --expect-kernels N: additionally require at least N kernels per input."""
     quiet = "--quiet" in paths
-    paths = [p for p in paths if p != "--quiet"]
-    total = 0
+    expect, min_ins = 1, MIN_INSTRUCTIONS
+    args = [p for p in paths if p != "--quiet"]
+    paths = []
+    k = 0
+    while k < len(args):
+        if args[k] == "--expect-kernels":
+            expect = int(args[k + 1]); k += 2
+        elif args[k].startswith("--expect-kernels="):
+            expect = int(args[k].split("=", 1)[1]); k += 1
+        elif args[k].startswith("--llvm-bin="):             # the LLVM tools of the compiler in use (csrc/cc_checked.sh passes them)
+            global LLVM
+            LLVM = args[k].split("=", 1)[1]; k += 1
+        elif args[k].startswith("--min-instructions="):      # (unit tests of the checker on hand-written snippets)
+            min_ins = int(args[k].split("=", 1)[1]); k += 1
+        else:
+            paths.append(args[k]); k += 1
+    if not paths:
+        print("check_exec_prologue.py: no input", file=sys.stderr)
+        return 2
+    total, unverified = 0, 0
     for p in paths:
-        for kind, f in code_objects(p):
+        nk = 0
+        cos = code_objects(p) if os.path.exists(p) else []
+        for kind, f in cos:
             ks = kernels_from_asm(f) if kind == "asm" else kernels_from_co(f)
             for name, ins in ks.items():
+                nk += 1
                 fnd = check(ins, labelled=(kind == "asm"))
                 dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
                 dem = re.sub(r"\(mpcq::DevModel.*", "", dem)
+                if len(ins) < min_ins:
+                    unverified += 1
+                    print(f"{os.path.basename(p)}: {dem}: NOT VERIFIED: only {len(ins)} instruction line(s) parsed")
                 if fnd:
                     total += len(fnd)
                     print(f"{os.path.basename(p)}: {dem}: {len(fnd)} block(s) with EXEC-dependent code in front of the EXEC restore")
                     for lab, bad, why in fnd[:6]:
                         print(f"    block {lab}: {why}: {len(bad)} instruction(s), e.g. {bad[0]} | {bad[-1]}")
-                elif not quiet:
+                elif not quiet and len(ins) >= min_ins:
                     print(f"{os.path.basename(p)}: {dem}: clean ({len(ins)} lines)")
-    return 1 if total else 0
+        if nk < expect:
+            unverified += 1
+            print(f"{os.path.basename(p)}: NOT VERIFIED: {nk} kernel(s) found in {len(cos)} gfx950 code object(s), expected at least {expect}")
+    if total:
+        return 1
+    return 2 if unverified else 0
 
 
 if __name__ == "__main__":
