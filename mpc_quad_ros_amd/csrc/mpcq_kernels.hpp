@@ -40,12 +40,6 @@ namespace mpcq {
 #ifndef MPCQ_UNROLL_SWEEP
 #define MPCQ_UNROLL_SWEEP 1
 #endif
-// fp32 QP: free-set stationarity (in units of eps * gradient scale) below which no refinement pass is attempted.
-// Measured on MI355X: 1 -> 8 takes the mean pass count from 2.5 to 1.7 (+16 % throughput) with the same worst-case
-// control deviation on the parity tests (1.3e-5); 32 and above let it grow to 7e-5.
-#ifndef MPCQ_F32_TOLS
-#define MPCQ_F32_TOLS 8
-#endif
 // The four Runge-Kutta substages of the shooting / prediction / plant integrators as ONE loop body (rolled) instead of four
 // inlined copies, and the substage loop of the sensitivity pass likewise: the step executes every phase once per control
 // period, so straight-line code is fetched from L2 every time (18 % of the wave cycles waited for instructions with
@@ -314,7 +308,7 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab, int mixed = 0)
   L.x0 = take(NX + 8);   // + [v_body(3), a_drag(3)] scratch of the post phase
   L.pre = take(NX + 5);  // what the post phase reads of the persistent state, fetched in the load phase: x_pred_prev(13) | statistics(4) | has_prev
   L.zd = L.dxd = 0;
-  if (mixed) { L.zd = take(N * NU); L.dxd = take((N + 1) * VS); }
+  if (mixed) L.zd = take(N * NU);   // (L.dxd: set below, it lives in the space of the float vectors dx | Dx)
   L.dbytes = o * 8;
   o = 0;
   const int nv = N * NU;
@@ -351,6 +345,9 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab, int mixed = 0)
   L.vin = take(N * VS);    // per-sweep input vector: slots 0..3 feed-forward k_i, slots 10..13 sweep-specific
   L.dx = take((N + 1) * VS);
   L.Dx = take((N + 1) * VS);
+  // mixed precision: the state trajectory in double, (N + 1) x 16 doubles = exactly the two float vectors dx | Dx, which only the
+  // interior point and the float factorisation's gap operand use -- never while dxd is live (polish_mixed).  Index in doubles from the LDS base.
+  if (mixed) L.dxd = (L.dbytes + L.dx * 4) / 8;
   if (L.gk) { L.K = gtake(N * KS); L.Linv = gtake(N * 16); }
   else { L.K = take(N * KS); L.Linv = take(N * 16); }
   L.sF = take(4 * VS);
@@ -951,7 +948,15 @@ __device__ inline void shoot_sens_t(const M& m, P<TR> S, P<TR> A, const Lds& L, 
 
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L) {
-  shoot_sens_t<C, typename ShootT<TQ>::T, TQ>(m, S, A, L, cN<C>(m));   // (arithmetic: see shoot_states)
+  // The float instances run THIS pass in float: what the double integration of shoot_states buys is the gap c_i (the residual of the
+  // dynamics, which the QP solution follows one to one); the sensitivities only shape the QP's curvature, and computed in float from the
+  // double pass's records they leave the control deviation where the double version does (measured on the saturating references that
+  // exposed the float state pass: 3e-7 either way).  -DMPCQ_MIXED_SENS64: in double as well.
+#ifdef MPCQ_MIXED_SENS64
+  shoot_sens_t<C, typename ShootT<TQ>::T, TQ>(m, S, A, L, cN<C>(m));
+#else
+  shoot_sens_t<C, TQ, TQ>(m, S, A, L, cN<C>(m));
+#endif
 }
 
 // ------------------------------------------------------------------ QP: vector sweeps
@@ -1925,164 +1930,6 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
   return settled;
 }
 
-// The same active-set method with Newton steps from the current point after every change of the working set (a state
-// rollout and a gradient sweep first): used for TQ = float, where increments keep their accuracy while a from-scratch
-// affine solve would have to be refined again every time.
-template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool polish_incremental(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, TQ gm, int& passes, const bool warm, const int max_passes, int& why PF_ARG) {
-  why = QPX_BUDGET;
-  bool fresh = false;
-  const int N = cN<C>(m), nv = N * NU, tid = lane_id();
-  if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
-    for (int i = tid; i < nv; i += 64) {
-      S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
-      S[L.z + i] = 0;
-    }
-  } else {      // working set identified by the interior point
-    for (int i = tid; i < nv; i += 64)
-      S[L.act + i] = S[L.ll + i] > m.pin_ratio * S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > m.pin_ratio * S[L.su + i] ? TQ(1) : TQ(0));
-  }
-  __syncthreads();
-  TQ tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;  // multiplier sign test
-  TQ tols = (sizeof(TQ) == 4 ? TQ(MPCQ_F32_TOLS) : TQ(64)) * m.eps * gm;   // stationarity on the free set (f32: refine until stagnation)
-  const TQ tolb = 16 * m.eps;       // bound proximity (bounds are O(1))
-  bool refactor = true, settled = false, full = false;
-  int nact = 1;   // pinned inputs in the working set (unknown before the first count)
-  // a bulk release that bounces straight back (the freed inputs violate and get pinned again) makes the next ones
-  // more selective: all wrong-signed multipliers -> those within 4x of the worst -> within 1.6x -> the worst only
-  int careful = 0;
-  bool released = false;
-  bool dx_done = false;   // the forward sweep already produced the state trajectory (affine pass)
-  bool incremental = false;   // the state trajectory has been updated by increments since it was last computed from z
-  TQ gF_prev = TQ(1e30);
-  for (passes = 0; passes < max_passes; ++passes) {
-    const bool aff = warm && passes == 0;
-    if (aff) {
-      // Warm start from z = 0 with every pinned input at a bound of exactly 0: the minimiser on the working set is the
-      // solution of the affine LQ problem itself (gaps c_i, gradients q_i, r_i in the recursion), so neither a state
-      // trajectory nor a gradient at z = 0 is needed first: one factorisation and one forward sweep.
-      int na = 0;
-      for (int i = tid; i < nv; i += 64) { S[L.rho + i] = S[L.r0 + i]; na += S[L.act + i] != TQ(0) ? 1 : 0; }
-      nact = wave_sum(na);
-      for (int it = tid; it < N * VS; it += 64) S[L.Dx + it] = (it & 15) < NX ? A[L.c + it] : TQ(0);   // gap of the affine pass (all pinned inputs sit at 0)
-      __syncthreads();
-      PF_START();
-      TQ gfac = 0;
-      const bool fok = riccati_factor<C, true, true>(m, S, A, Kb, L PF_PASS, &gfac);
-      PF_STOP(PF_FACTOR);
-      if (!fok) { why = QPX_NUMERIC; return false; }
-      gm = tmax(TQ(1), gfac);
-      tolm = (sizeof(TQ) == 4 ? TQ(8) : TQ(64)) * m.eps * gm;
-      tols = (sizeof(TQ) == 4 ? TQ(MPCQ_F32_TOLS) : TQ(64)) * m.eps * gm;
-      refactor = false;
-      PF_START(); riccati_forward<C, true>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
-      dx_done = true;
-    } else if (full) {
-      // the last pass took a full Newton step with an unchanged working set: the state trajectory is affine in z
-      if (!dx_done) {
-        for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += S[L.Dx + i];
-        __syncthreads();
-        incremental = true;
-      }
-      dx_done = false;
-      if (sizeof(TQ) == 8 && nact == 0) { settled = true; break; }   // no multipliers to check, step exact to f64 rounding
-      PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
-    } else {
-      dx_done = false;
-      for (int i = tid; i < nv; i += 64) {
-        const TQ a = S[L.act + i];
-        if (a < 0) S[L.z + i] = S[L.lb + i];
-        else if (a > 0) S[L.z + i] = S[L.ub + i];
-      }
-      __syncthreads();
-      if (!fresh) {
-        PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-        PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
-        incremental = false;
-      }
-    }
-    fresh = false;
-    if (!aff) {
-    // stationarity on the free set, worst multiplier sign violation on the pinned set
-    TQ gF = 0, vmax = 0;
-    int na = 0;
-    for (int i = tid; i < nv; i += 64) {
-      const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
-      if (a == TQ(0)) gF = tmax(gF, tabs(g));
-      else { vmax = tmax(vmax, a < 0 ? -g : g); na += 1; }
-    }
-    gF = wave_max(gF);
-    vmax = wave_max(vmax);
-    nact = wave_sum(na);
-    if (!(gF == gF)) { why = QPX_NUMERIC; return false; }
-#ifdef MPCQ_EMU_DEBUG
-    if (tid == 0) { int na = 0; for (int i = 0; i < nv; ++i) na += S[L.act + i] != TQ(0); printf("  polish pass %d warm %d full %d gF %.3e vmax %.3e tolm %.3e tols %.3e nact %d\n", passes, (int)warm, (int)full, (double)gF, (double)vmax, (double)tolm, (double)tols, na); }
-#endif
-    if (full) {
-      // the point minimises the QP on the working set: multipliers are meaningful here only
-      if (vmax > tolm) {
-        const TQ rel_thr = careful == 0 ? TQ(0) : (careful == 1 ? TQ(0.25) * vmax : (careful == 2 ? TQ(0.625) * vmax : vmax));
-        for (int i = tid; i < nv; i += 64) {
-          const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
-          const TQ v = a < 0 ? -g : g;
-          if (a != TQ(0) && v > tolm && v >= rel_thr) S[L.act + i] = 0;   // release wrong-signed multipliers
-        }
-        refactor = true;
-        released = true;
-        gF_prev = TQ(1e30);
-        __syncthreads();
-      } else if (gF <= tols || gF > TQ(0.25) * gF_prev) {
-        settled = true;  // stationary to rounding, or the Newton refinement stagnated at the rounding level
-        break;
-      } else {
-        gF_prev = gF;
-      }
-    }
-    for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
-    __syncthreads();
-    PF_START();
-    if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, Kb, L PF_PASS); PF_STOP(PF_FACTOR); if (!fok) { why = QPX_NUMERIC; return false; } }
-    else { riccati_backward_vec<C>(m, S, A, Kb, L, true); PF_STOP(PF_BWD); }
-    refactor = false;
-    PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
-    }
-    TQ alpha = 1;
-    for (int i = tid; i < nv; i += 64) {
-      if (S[L.act + i] != TQ(0)) continue;
-      const TQ d = S[L.dz + i], z = S[L.z + i];
-      if (d < 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.lb + i] - z) / d));
-      if (d > 0) alpha = tmin(alpha, tmax(TQ(0), (S[L.ub + i] - z) / d));
-    }
-    alpha = wave_min(alpha);
-    // full Newton step; if it leaves the box, clip and pin EVERY violator at once (the minimiser on a working
-    // set does not depend on the starting point, so only the sequence of working sets matters)
-    int nblk = 0;
-    for (int i = tid; i < nv; i += 64) {
-      if (S[L.act + i] != TQ(0)) continue;
-      const TQ lb = S[L.lb + i], ub = S[L.ub + i];
-      TQ z = S[L.z + i] + S[L.dz + i];
-      if (alpha < TQ(1)) {
-        if (z <= lb + tolb) { z = lb; S[L.act + i] = -1; nblk += 1; }
-        else if (z >= ub - tolb) { z = ub; S[L.act + i] = 1; nblk += 1; }
-      }
-      S[L.z + i] = z;
-    }
-    nblk = wave_sum(nblk);
-#ifdef MPCQ_EMU_DEBUG
-    if (tid == 0) printf("     alpha %.6e nblk %d\n", (double)alpha, nblk);
-#endif
-    full = nblk == 0;
-    if (released && nblk >= 8 && 2 * (nact + nblk) >= nv) { why = QPX_BOUNCE; return false; }   // wholesale bounce in a saturated regime: leave it to the interior point
-    if (nblk > 0) { refactor = true; if (released && careful < 3) careful += 1; }
-    released = false;
-    __syncthreads();
-  }
-  if (settled && sizeof(TQ) == 4 && incremental) {   // f32: replace the incrementally updated trajectory by a fresh rollout of the final z
-    PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-  }
-  return settled;
-}
-
 // ------------------------------------------------------------------ mixed precision (TQ = float): fp64 residuals on the float stage records
 // The float Riccati factorisation is a preconditioner: cond(H) ~ 2e6, so a solve in float alone carries 1e-5 .. 1e-2 of error in du
 // (hard part 1b).  The solution is therefore kept in double (D[L.zd], D[L.dxd]) and refined against the residual
@@ -2179,12 +2026,163 @@ MPCQ_PHASE void adjoint64(const DevModel<float>& m, P<double> D, P<float> S, P<f
   vmax = wave_max(vm);
 }
 
-// Active-set method of the mixed-precision mode (TQ = float): the working-set logic of polish_incremental -- affine first pass of a warm
-// attempt, Newton steps of the float factorisation with a ratio test, pins, releases -- with the iterate in double (D[L.zd]) and every
-// residual evaluated in double (rollout64 / adjoint64).  A pass at a minimiser candidate (no pin in the step that led to it) is one
-// step of iterative refinement; the method settles when the correction it takes is below tol_c (the remaining error is that times the
-// contraction, a few per cent) or when the residual says the previous one already was.  Multiplier signs are judged on the double
-// values.  On success D[L.zd], D[L.dxd] hold the solution, S[L.z] its float image.
+// Forward sweep of the float gains with the vector in double (see riccati_forward for the lane roles):
+//   affine:  z_i = K_i dx_i + k_i (pinned inputs: exactly their bound, 0 in a warm attempt), dx_{i+1} = A dx_i + B z_i + c_i from dx_0 = D[L.dxd + 0..15]
+//            -> D[L.zd], D[L.dxd]: solution of the affine LQ problem on the working set and ITS OWN state rollout, consistent to double rounding;
+//   !affine: dz_i = K_i Dx_i + k_i, Dx_{i+1} = A Dx_i + B dz_i from Dx_0 = 0 -> S[L.dz] (float) and D[L.dxd] += Dx: the trajectory follows
+//            the correction inside the sweep (the rollout is linear), so no rollout64 is needed behind a refinement step.
+template <typename C, bool affine, bool GAB = C::GAB>
+MPCQ_PHASE void riccati_forward64(const DevModel<float>& m, P<double> D, P<float> S, P<float> A, P<float> Kb, const Lds& L PF_ARG) {
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
+  const RMaj<float> rm(L.AB + N * ABS, L.AB, ABS, NX, h, c);
+  constexpr int PD = Depth<GAB>::PD;
+  const bool prow = c >= 10 && c < NX;
+  // float slot map: lane row 2 holds inputs 0, 1 in registers 2, 3, row 3 inputs 2, 3 in registers 0, 1; each of the two rows computes its own pair
+  const int j0 = h == 3 ? 2 : 0, j1 = j0 + 1;
+  const bool hasu = h >= 2;
+  const int ko0 = L.K + j0 * ABW + c, ko1 = L.K + j1 * ABW + c;
+  constexpr int KD = C::GK ? PD : 1;
+  double xc = affine ? D[L.dxd + c] : 0.0;
+  float qa[PD + 1][4], kq0[KD + 1], kq1[KD + 1], qc[PD + 1], g0, g1, p0 = 0, p1 = 0;
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int id = d < N ? d : N - 1;
+    rm.load(A, id, qa[d]);
+    qc[d] = affine ? A[L.c + id * VS + c] : 0.0f;
+  }
+#pragma unroll
+  for (int d = 0; d < KD; ++d) {
+    const int id = d < N ? d : N - 1;
+    kq0[d] = Kb[ko0 + id * KS];
+    kq1[d] = Kb[ko1 + id * KS];
+  }
+  g0 = S[L.vin + j0]; g1 = S[L.vin + j1];
+  if (affine) { p0 = S[L.rt + j0]; p1 = S[L.rt + j1]; }
+#pragma unroll MPCQ_UNROLL_SWEEP
+  for (int i = 0; i < N; ++i) {
+    const int ip = i + 1 < N ? i + 1 : i, ig = i + PD < N ? i + PD : N - 1, ik = i + KD < N ? i + KD : N - 1;
+    rm.load(A, ig, qa[PD]);
+    qc[PD] = affine ? A[L.c + ig * VS + c] : 0.0f;
+    kq0[KD] = Kb[ko0 + ik * KS];
+    kq1[KD] = Kb[ko1 + ik * KS];
+    const float g0n = S[L.vin + ip * VS + j0], g1n = S[L.vin + ip * VS + j1];
+    float p0n = 0, p1n = 0;
+    if (affine) { p0n = S[L.rt + ip * NU + j0]; p1n = S[L.rt + ip * NU + j1]; }
+    double u0 = rowsum((double)kq0[0] * xc) + (double)g0, u1 = rowsum((double)kq1[0] * xc) + (double)g1;
+    if (affine) { u0 = p0 < 0.0f ? 0.0 : u0; u1 = p1 < 0.0f ? 0.0 : u1; }   // pinned (R~ < 0): held at the bound, exactly
+    double xv[4];
+    l2g<float>(xc, h, xv);
+    const double v0 = h == 3 ? u0 : xv[0], v1 = h == 3 ? u1 : xv[1];
+    const double v2 = h < 2 ? xv[2] : (h == 2 ? u0 : 0.0), v3 = h < 2 ? xv[3] : (h == 2 ? u1 : 0.0);
+    const double ta = ((double)qa[0][0] * v0 + (double)qa[0][1] * v1) + ((double)qa[0][2] * v2 + (double)qa[0][3] * v3);
+    if (c == 0 && hasu) {
+      if (affine) { D[L.zd + i * NU + j0] = u0; D[L.zd + i * NU + j1] = u1; }
+      else { S[L.dz + i * NU + j0] = (float)u0; S[L.dz + i * NU + j1] = (float)u1; }
+    }
+    double xn = hsum(ta) + (prow ? xc : 0.0) + (affine ? (double)qc[0] : 0.0);
+    xn = c < NX ? xn : 0.0;
+    xc = xn;
+    if (lane < VS) {
+      if (affine) D[L.dxd + (i + 1) * VS + lane] = xn;
+      else D[L.dxd + (i + 1) * VS + lane] += xn;
+    }
+    g0 = g0n; g1 = g1n; p0 = p0n; p1 = p1n;
+    shift<float, PD>(qa);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) qc[d] = qc[d + 1];
+#pragma unroll
+    for (int d = 0; d < KD; ++d) { kq0[d] = kq0[d + 1]; kq1[d] = kq1[d + 1]; }
+  }
+  __syncthreads();
+}
+// adjoint64 and the backward vector recursion of the float factorisation (riccati_backward_vec, polish form) as ONE backward sweep: the
+// gradient of stage i is the linear term of the recursion at stage i, both recursions read the same operand registers, and their two
+// dependent chains interleave.  Used when the factorisation in K / Lambda^-1 belongs to the current working set.
+template <typename C, bool GAB = C::GAB>
+MPCQ_PHASE void adjoint64_bwd(const DevModel<float>& m, P<double> D, P<float> S, P<float> A, P<float> Kb, const Lds& L, double& gF, double& vmax) {
+  const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
+  const KMaj<float> km(L, N, h, c);
+  constexpr int PD = Depth<GAB>::PD;
+  constexpr int KD = C::GK ? PD : 0;
+  const bool arow = c < 10, prow = c >= 10 && c < NX, ucol = c >= 10 && c < 14;
+  const int j = ucol ? c - 10 : 0, lj = lane < NU ? lane : 0;
+  const double qdc = (double)S[L.wq + c], ru = (double)S[L.wq + 2 * VS + j];
+  double pc = (double)S[L.wq + VS + c] * D[L.dxd + N * VS + c] + (double)A[L.qv + N * VS + c];   // costate of the objective
+  float pr = 0;                                                                                  // vector of the Riccati recursion
+  float qa[PD + 1][4], qq[PD + 1], kq[KD + 1];
+  V4<float> lq[KD + 1];
+  double gf = 0, vm = 0;
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int id = N - 1 - d > 0 ? N - 1 - d : 0;
+    km.load(A, id, qa[d]);
+    qq[d] = A[L.qv + id * VS + c];
+  }
+#pragma unroll
+  for (int d = 0; d < KD; ++d) {
+    const int id = N - 1 - d > 0 ? N - 1 - d : 0;
+    kq[d] = Kb[L.K + id * KS + h * ABW + c];
+    lq[d] = ld4(Kb, L.Linv + id * 16 + lj * 4);
+  }
+#pragma unroll MPCQ_UNROLL_SWEEP
+  for (int i = N - 1; i >= 0; --i) {
+    const int ip = i - PD > 0 ? i - PD : 0, ik = i - KD > 0 ? i - KD : 0;
+    km.load(A, ip, qa[PD]);
+    qq[PD] = A[L.qv + ip * VS + c];
+    kq[KD] = Kb[L.K + ik * KS + h * ABW + c];
+    lq[KD] = ld4(Kb, L.Linv + ik * 16 + lj * 4);
+    const double dxc = D[L.dxd + i * VS + c];
+    const double gvc = ucol ? ru * D[L.zd + i * NU + j] + (double)S[L.r0 + i * NU + j] : 0.0;
+    const float a = S[L.act + i * NU + j], rtj = S[L.rt + i * NU + lj];
+    // ---- gradient (double)
+    double pi[4];
+    l2g<float>(pc, h, pi);
+    const double t = hsum(((double)qa[0][0] * pi[0] + (double)qa[0][1] * pi[1]) + ((double)qa[0][2] * pi[2] + (double)qa[0][3] * pi[3]));   // (AB''^T p)[c]
+    const double g = t + gvc;
+    if (lane < VS) S[L.grad + i * VS + lane] = (float)g;
+    if (ucol) {
+      double ag = fabs(g);
+      if (!(ag == ag)) ag = 1e308;
+      if (a == 0.0f) gf = ag > gf ? ag : gf;
+      else { const double v = a < 0.0f ? -g : g; vm = v > vm ? v : vm; gf = ag >= 1e308 ? ag : gf; }
+    }
+    pc = (arow ? t : (prow ? pc : 0.0)) + (qdc * dxc + (double)qq[0]);
+    // ---- feed-forward of the correction (float): rho_i = the gradient just formed
+    float pv[4];
+    l2g<float>(pr, h, pv);
+    const float tr = hsum((qa[0][0] * pv[0] + qa[0][1] * pv[1]) + (qa[0][2] * pv[2] + qa[0][3] * pv[3]));
+    const float gt = tr + (ucol ? (float)g : 0.0f);              // gt_j = rho_j + (B^T p)_j on lane column 10 + j
+    float r = dpp_rows<0x12F, 0xA>(gt, h);
+    r = dpp_rows<0x12E, 0xC>(r, h);
+    const float gh = dpp<0x15A>(r);                              // row h: gt_h on every lane
+    pr = (arow ? tr : (prow ? pr : 0.0f)) + hsum(kq[0] * gh);    // p_i = A^T p_{i+1} + K^T gt (pinned rows of K are 0)
+    float gg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gg[q] = bc(gt, 10 + q);
+    if (lane < NU) {
+      const V4<float> li = lq[0];
+      const float kvj = -(li.a * gg[0] + li.b * gg[1] + li.c * gg[2] + li.d * gg[3]);
+      S[L.vin + i * VS + lane] = rtj < 0.0f ? 0.0f : kvj;
+    }
+    shift<float, PD>(qa);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) qq[d] = qq[d + 1];
+#pragma unroll
+    for (int d = 0; d < KD; ++d) { kq[d] = kq[d + 1]; lq[d] = lq[d + 1]; }
+  }
+  __syncthreads();
+  gF = wave_max(gf);
+  vmax = wave_max(vm);
+}
+
+// Active-set method of the mixed-precision mode (TQ = float).  Working-set logic as in the fp64 method's ancestors: affine first pass of a
+// warm attempt, Newton steps of the float factorisation with a bound test, pins, releases of wrong-signed multipliers at a minimiser --
+// with the iterate in double (D[L.zd], D[L.dxd]) and every residual evaluated in double.  A pass at a minimiser candidate (no pin in the
+// step that led to it) is one step of iterative refinement: gradient + feed-forward in one backward sweep (adjoint64_bwd), correction and
+// trajectory update in one forward sweep (riccati_forward64).  It settles when the correction it has just taken is below tol_c (what is
+// left is that times the contraction, a few per cent), or when the residual says the previous one already was.  Multiplier signs are
+// judged on the double values.  A warm solve without a change of the working set costs one factorisation and three sweeps.
+// On success D[L.zd], D[L.dxd] hold the solution, S[L.z] its float image.
 #ifndef MPCQ_MIXED_TOLC
 #define MPCQ_MIXED_TOLC 1e-5
 #endif
@@ -2193,29 +2191,25 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
                              const int max_passes, int& why, int& converged, const bool last_resort PF_ARG) {
   using TQ = float;
   why = QPX_BUDGET;
-  converged = 1;
   const int N = cN<C>(m), nv = N * NU, tid = lane_id();
   auto lbd = [&](int i) { return m.ulb[i & 3] - D[L.U + i]; };   // bounds of du in double (S[L.lb], S[L.ub] are their float images)
   auto ubd = [&](int i) { return m.uub[i & 3] - D[L.U + i]; };
   if (warm) {   // working set = inputs the previous iterate left exactly on a bound; start from z = 0 (feasible)
-    for (int i = tid; i < nv; i += 64) {
-      S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
-      D[L.zd + i] = 0;
-    }
+    for (int i = tid; i < nv; i += 64) S[L.act + i] = S[L.lb + i] == TQ(0) ? TQ(-1) : (S[L.ub + i] == TQ(0) ? TQ(1) : TQ(0));
   } else {      // working set identified by the interior point, which is also the starting point
     for (int i = tid; i < nv; i += 64) {
       S[L.act + i] = S[L.ll + i] > m.pin_ratio * S[L.sl + i] ? TQ(-1) : (S[L.lu + i] > m.pin_ratio * S[L.su + i] ? TQ(1) : TQ(0));
       D[L.zd + i] = (double)S[L.z + i];
     }
   }
-  if (tid < VS) D[L.dxd + tid] = tid < NX ? D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)] : 0.0;   // dx_0 = x_meas - X_0, not rounded to float
-  __syncthreads();
-  double tolm = 1e-8 * (double)gm;   // multiplier sign test (on double residuals)
+  double tolm = 1e-12 * (double)gm;   // multiplier sign test: the multipliers come from double residuals (the fp64 method: 64 eps gm = 7e-15 gm)
   const double tolb = 16 * (double)m.eps;   // bound proximity of a pin (bounds are O(1))
   const double tol_c = MPCQ_MIXED_TOLC, tol_z = 1e-6;
   bool refactor = true, settled = false, full = false, released = false;
+  bool need_roll = true;              // D[L.dxd] is not the state trajectory of D[L.zd] (z was changed outside a sweep)
   int nact = 1, careful = 0;
   double gF_prev = -1, dz_prev = 0;   // residual and correction of the previous refinement step on this working set (< 0: none)
+  auto set_dx0 = [&]() { if (tid < VS) D[L.dxd + tid] = tid < NX ? D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)] : 0.0; };   // dx_0 = x_meas - X_0, in double
   for (passes = 0; passes < max_passes; ++passes) {
     const bool aff = warm && passes == 0;
     bool corrected = false;
@@ -2226,7 +2220,7 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
       int na = 0;
       for (int i = tid; i < nv; i += 64) { S[L.rho + i] = S[L.r0 + i]; na += S[L.act + i] != TQ(0) ? 1 : 0; }
       nact = wave_sum(na);
-      for (int it = tid; it < N * VS; it += 64) S[L.Dx + it] = (it & 15) < NX ? A[L.c + it] : TQ(0);
+      for (int it = tid; it < N * VS; it += 64) S[L.Dx + it] = (it & 15) < NX ? A[L.c + it] : TQ(0);   // gap operand of the factorisation
       __syncthreads();
       PF_START();
       TQ gfac = 0;
@@ -2234,9 +2228,12 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
       PF_STOP(PF_FACTOR);
       if (!fok) { why = QPX_NUMERIC; return false; }
       gm = tmax(TQ(1), gfac);
-      tolm = 1e-8 * (double)gm;
+      tolm = 1e-12 * (double)gm;
       refactor = false;
-      PF_START(); riccati_forward<C, true>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+      set_dx0();   // (behind the factorisation: D[L.dxd] shares its space with the gap operand)
+      __syncthreads();
+      PF_START(); riccati_forward64<C, true>(m, D, S, A, Kb, L PF_PASS); PF_STOP(PF_FWD);
+      need_roll = false;
     } else {
       int na = 0;
       for (int i = tid; i < nv; i += 64) {
@@ -2246,9 +2243,18 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
         na += a != TQ(0) ? 1 : 0;
       }
       nact = wave_sum(na);
-      __syncthreads();
-      PF_START(); rollout64<C>(m, D, S, A, L); PF_STOP(PF_ROLL);
-      PF_START(); adjoint64<C>(m, D, S, A, L, gF, vmax); PF_STOP(PF_ADJ);
+      if (need_roll) {
+        set_dx0();
+        __syncthreads();
+        PF_START(); rollout64<C>(m, D, S, A, L); PF_STOP(PF_ROLL);
+        need_roll = false;
+      } else __syncthreads();
+      // residual of the QP at zd in double; with a factorisation of this working set at hand, the feed-forward of the correction in the same sweep
+      const bool fused = !refactor;
+      PF_START();
+      if (fused) adjoint64_bwd<C>(m, D, S, A, Kb, L, gF, vmax);
+      else adjoint64<C>(m, D, S, A, L, gF, vmax);
+      PF_STOP(PF_ADJ);
       if (!(gF < 1e300)) { why = QPX_NUMERIC; return false; }
 #ifdef MPCQ_EMU_DEBUG
       if (tid == 0) printf("  mixed pass %d warm %d full %d gF %.3e vmax %.3e tolm %.3e nact %d (prev gF %.3e dz %.3e)\n", passes, (int)warm, (int)full, gF, vmax, tolm, nact, gF_prev, dz_prev);
@@ -2276,13 +2282,16 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
       }
       released = rel_now;
       if (rel_now) gF_prev = -1;
-      for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
-      __syncthreads();
-      PF_START();
-      if (refactor) { const bool fok = riccati_factor<C, true>(m, S, A, Kb, L PF_PASS); PF_STOP(PF_FACTOR); if (!fok) { why = QPX_NUMERIC; return false; } }
-      else { riccati_backward_vec<C>(m, S, A, Kb, L, true); PF_STOP(PF_BWD); }
-      refactor = false;
-      PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+      if (refactor) {
+        for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
+        __syncthreads();
+        PF_START();
+        const bool fok = riccati_factor<C, true>(m, S, A, Kb, L PF_PASS);
+        PF_STOP(PF_FACTOR);
+        if (!fok) { why = QPX_NUMERIC; return false; }
+        refactor = false;
+      }
+      PF_START(); riccati_forward64<C, false>(m, D, S, A, Kb, L PF_PASS); PF_STOP(PF_FWD);
       corrected = full && !rel_now;
     }
     // full Newton step; if it leaves the box, clip and pin EVERY violator at once
@@ -2290,7 +2299,7 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
     double dzm = 0;
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
-      const double d = (double)S[L.dz + i], zn = D[L.zd + i] + d;
+      const double d = aff ? D[L.zd + i] : (double)S[L.dz + i], zn = aff ? d : D[L.zd + i] + d;
       if (!(zn == zn)) viol |= 2;
       if (zn < lbd(i) || zn > ubd(i)) viol |= 1;
       dzm = fabs(d) > dzm ? fabs(d) : dzm;
@@ -2302,7 +2311,7 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
       const double lb = lbd(i), ub = ubd(i);
-      double z = D[L.zd + i] + (double)S[L.dz + i];
+      double z = aff ? D[L.zd + i] : D[L.zd + i] + (double)S[L.dz + i];
       if (viol) {
         if (z <= lb + tolb) { z = lb; S[L.act + i] = -1; nblk += 1; }
         else if (z >= ub - tolb) { z = ub; S[L.act + i] = 1; nblk += 1; }
@@ -2316,14 +2325,10 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
     full = nblk == 0;
     // wholesale bounce in a saturated regime: leave it to the interior point (not behind its final iterations: last_resort)
     if (released && nblk >= 8 && 2 * (nact + nblk) >= nv && !last_resort) { why = QPX_BOUNCE; return false; }
-    if (nblk > 0) { refactor = true; gF_prev = -1; if (released && careful < 3) careful += 1; }
+    if (nblk > 0) { refactor = true; need_roll = true; gF_prev = -1; if (released && careful < 3) careful += 1; }   // clipped inputs: the sweep's trajectory is not theirs
     released = false;
     if (corrected && full) {
-      if (dzm <= tol_c) {   // the state trajectory follows the correction (the sweep's own Dx)
-        for (int it = tid; it < (N + 1) * VS; it += 64) D[L.dxd + it] += (double)S[L.Dx + it];
-        settled = true; passes += 1;
-        break;
-      }
+      if (dzm <= tol_c) { settled = true; passes += 1; break; }   // (the forward sweep has taken the trajectory along)
       gF_prev = gF; dz_prev = dzm;
     }
     __syncthreads();
@@ -2381,6 +2386,15 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
     wpasses += 1000;
   }
   int st = 0;
+  // float: the refined solution's state trajectory D[L.dxd] shares its space with the float vectors dx | Dx; behind an active-set attempt
+  // that did not settle, dx_0 = x_meas - X_0 is put back in front of the float rollout
+  auto restore_dx0 = [&]() {
+    if constexpr (sizeof(TQ) == 4) {
+      if (tid < VS) S[L.dx + tid] = tid < NX ? (TQ)(D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)]) : TQ(0);
+      __syncthreads();
+    }
+  };
+  restore_dx0();
   // interior start
   for (int i = tid; i < nv; i += 64) {
     const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
@@ -2407,6 +2421,7 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
+      restore_dx0();
       PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
       PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
       st = ipm_run<C>(m, S, A, Kb, L, m.qp_tol, gm, it PF_PASS);
@@ -2544,7 +2559,8 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   if (tid == 0 && b == 0 && st.chk) { const unsigned long long pc = __builtin_amdgcn_s_getpc(); st.chk[9] = (int)(unsigned)pc; st.chk[10] = (int)(unsigned)(pc >> 32); }
   __syncthreads();
 #endif
-  const P<double> D = mk(reinterpret_cast<double*>(smem_raw + CK_HDR), L.dbytes / 8, CK_LDS_D);
+  // (float instances: the double view extends over the TQ region, where the state trajectory of the refined QP solution lives: L.dxd)
+  const P<double> D = mk(reinterpret_cast<double*>(smem_raw + CK_HDR), sizeof(TQ) == 4 ? (L.dbytes + L.qtotal * 4) / 8 : L.dbytes / 8, CK_LDS_D);
   const P<TQ> S = mk(reinterpret_cast<TQ*>(smem_raw + CK_HDR + L.dbytes), L.qtotal, CK_LDS_Q);
   const P<TQ> G = mk(st.stage + (size_t)b * L.gtotal, L.gtotal, CK_STAGE);   // per-instance record in global memory
   const P<TQ> A = GAB ? G : S;   // base of the stage records
