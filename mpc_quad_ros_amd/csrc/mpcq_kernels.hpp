@@ -170,6 +170,16 @@ constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the 
 constexpr int VS = 16;           // stride of state-sized QP vectors (internal order, 13 used)
 constexpr int ABS = NX * ABW;    // per-stage stride of AB'
 constexpr int PST = 256 + VS;     // stride of a stored cost-to-go (see Lds::pst)
+// Cost-to-go tiles are kept for the stages i = 1 (mod PSTEP) only: a factorisation that has to restart below a changed stage t restarts at
+// the next multiple of PSTEP at or above t (from the tile of the stage above it), i.e. revisits at most PSTEP - 1 stages more than the
+// change requires -- and writes a quarter of the tiles (2.2 KB each in fp64; at N = 20 the tiles were 43 KB of the ~100 KB a quadrotor
+// wrote per period).  A restart from an exact copy of the tile reproduces the full factorisation bit for bit, whatever the spacing.
+constexpr int PSTEP = 4;
+__host__ __device__ inline int pst_first(int N, int start, int pst_valid) {   // stage a factorisation (re)starts at; N - 1: from the top
+  if (start < 0) return N - 1;
+  const int f = (start + PSTEP - 1) & ~(PSTEP - 1);
+  return (f < N - 1 && f + 1 <= pst_valid) ? f : N - 1;
+}
 constexpr int MROW = 20;          // stride of a multiplier row (see Lds::mrow)
 constexpr int KS = NU * ABW;     // per-stage stride of K (4 rows of 13, padded to 16)
 // per (stage, RK substage) record of the shooting pass, what the sensitivity pass reads: q_s(4) r_s(3) | d vdot/dq (3x4) | d vdot/dv (3x3) | R[:,2]
@@ -327,10 +337,7 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab, int mixed = 0)
     L.gx = L.AB;   // exchange scratch of shoot_states: AB'' is not written before shoot_sens
   }
   L.mrow = gtake(N * MROW * NU);
-  L.pst = gtake(N * PST);
-#ifdef MPCQ_AB_PSTORE_DOUBLE   // A/B measurement only: every cost-to-go tile is written twice (what do the stores cost?)
-  gtake(N * PST);
-#endif
+  L.pst = gtake(((N + PSTEP - 1) / PSTEP) * PST);   // one tile per PSTEP stages (pst_first)
   if (!L.gk) { L.r0 = take(nv); L.lb = take(nv); L.ub = take(nv); }
   L.alpha = take(3 * nb);
   L.basis = take(3 * nb);
@@ -1220,7 +1227,7 @@ template <typename TQ> __device__ inline TQ pin_diag() { return sizeof(TQ) == 8 
 // that need it.  Returns false if a stage Hessian was not positive definite.
 template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L PF_ARG, TQ* gscale = nullptr, P<TQ> mrows = nullptr,
-                                      P<TQ> pstore = nullptr, int start = -1, bool have_rt = false) {
+                                      P<TQ> pstore = nullptr, int start = -1, bool have_rt = false, const int pst_valid = 1 << 30, const int pst_store = 1 << 30) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   bool ok = true;
@@ -1240,7 +1247,9 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
   // Restart: the recursion above the highest stage whose working set changed is unchanged, so it resumes from the
   // cost-to-go (P_{start+1}, p_{start+1}) the previous factorisation stored (K_i, Lambda_i^-1, k_i of the stages
   // above are still in LDS).
-  const int first = (pstore && start >= 0 && start < N - 1) ? start : N - 1;
+  // (pst_valid: highest stage whose stored tile is current; pst_store: tiles are kept for stages up to this one only -- the caller knows
+  //  above which stage the working set cannot change, and a cost-to-go tile is 2 KB of global stores)
+  const int first = pstore ? pst_first(N, start, pst_valid) : N - 1;
   const bool resumed = first < N - 1;
   int toff[4];
   const bool cq = c < 10, cp = c >= 10 && c < NX;
@@ -1249,7 +1258,7 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
     const int row = RI<TQ>(s, h);
     const bool rq = row < 10, rp = row >= 10 && row < NX;
     Pop[s] = (row == c && c < NX) ? S[L.wq + VS + c] : TQ(0);
-    if (resumed) { Pop[s] = pstore[(first + 1) * PST + lane * 4 + s]; pv[s] = pstore[(first + 1) * PST + 256 + (row < VS ? row : 0)]; }
+    if (resumed) { Pop[s] = pstore[(first / PSTEP) * PST + lane * 4 + s]; pv[s] = pstore[(first / PSTEP) * PST + 256 + (row < VS ? row : 0)]; }   // tile of stage first + 1
     qdg[s] = (row == c && c < NX) ? S[L.wq + c] : TQ(0);
     mA2[s] = (cq && rq) ? TQ(1) : TQ(0);
     mA1[s] = (cq && rp) ? TQ(1) : TQ(0);
@@ -1449,16 +1458,12 @@ MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb
       }
     }
     if (i == 0) break;
-    if (pstore) {   // cost-to-go of this stage, for a later restart below it
+    if (pstore && i <= pst_store && (i & (PSTEP - 1)) == 1) {   // cost-to-go of this stage, for a later restart below it
 #pragma unroll
-      for (int s = 0; s < 4; ++s) pstore[i * PST + lane * 4 + s] = Pop[s];
-#ifdef MPCQ_AB_PSTORE_DOUBLE
-#pragma unroll
-      for (int s = 0; s < 4; ++s) pstore[(N + i) * PST + lane * 4 + s] = Pop[s];
-#endif
+      for (int s = 0; s < 4; ++s) pstore[(i / PSTEP) * PST + lane * 4 + s] = Pop[s];
       if (vl) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) pstore[i * PST + 256 + RI<TQ>(s, h)] = pv[s];
+        for (int s = 0; s < 4; ++s) pstore[(i / PSTEP) * PST + 256 + RI<TQ>(s, h)] = pv[s];
       }
     }
     __syncthreads();   // the hand-over arrays are rewritten by the next stage
@@ -1735,6 +1740,8 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
   unsigned relmask = 0;   // bit k: input tid + 64 k was released in the previous pass (a bounce = it is pinned again in this one)
   int top = N - 1;   // highest stage whose working set changed since the last factorisation (N-1: factorise everything)
   bool keep_p = false;
+  int ptop = -1;     // highest stage whose working set may change (tiles are kept for stages <= ptop + 1)
+  int pst_hi = -1;   // highest stage whose stored cost-to-go tile is current
   for (passes = 0; passes < max_passes; ++passes) {
     {
       // New working set.  Its minimiser is the solution of the affine LQ problem with the pinned inputs held at their
@@ -1760,10 +1767,14 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
         // Cost-to-go tiles are kept (43 KB of global stores) only where a change of the working set is likely: some
         // input pinned already, or a free one within `margin` of a bound.  Elsewhere a change (rare) refactorises from
         // the top as before.
-        TQ dmin = 1;
+        // ... and only up to the highest such stage: the recursion runs from the last stage down, a restart at stage t needs the tile
+        // of stage t + 1, and above the highest stage that can change nothing is ever restarted (a change up there, rare, refactorises
+        // from the top and extends the range).  On the bench workload the saturated inputs sit in the first stages of the horizon.
+        int hi = -1;
         for (int i = tid; i < nv; i += 64)
-          if (S[L.act + i] == TQ(0)) dmin = tmin(dmin, tmin(-S[L.lb + i], S[L.ub + i]));
-        keep_p = nact > 0 || wave_min(dmin) < TQ(0.1);
+          if (S[L.act + i] != TQ(0) || tmin(-S[L.lb + i], S[L.ub + i]) < TQ(0.1)) hi = i >> 2;   // (ascending i per lane: the last hit is the highest)
+        ptop = wave_max(hi);
+        keep_p = ptop >= 0;
 #ifdef MPCQ_AB_NO_PSTORE   // A/B measurement only: no cost-to-go tiles, every factorisation starts at the last stage
         keep_p = false;
 #endif
@@ -1786,10 +1797,14 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
       PF_START();
       TQ gfac = 0;
 #if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD) && !defined(MPCQ_PROFILE_FAC)
-      pf.acc[13] += (keep_p && top >= 0 && top < N - 1) ? top + 1 : N;   // stages this factorisation visits
+      pf.acc[13] += (keep_p ? pst_first(N, top, pst_hi) : N - 1) + 1;   // stages this factorisation visits
       pf.acc[14] += 1;                                                    // factorisations
 #endif
-      const bool fok = riccati_factor<C, true, true>(m, S, A, Kb, L PF_PASS, &gfac, nact > 0 ? G + L.mrow : P<TQ>(nullptr), keep_p ? G + L.pst : P<TQ>(nullptr), top);
+      if (passes > 0 && top > ptop) ptop = top;   // a change above the range: this factorisation starts at the top (no tile there) and stores up to it
+      const int pst_store = ((ptop + PSTEP - 1) & ~(PSTEP - 1)) + 1;   // the tile a restart at or below ptop can need
+      const bool fok = riccati_factor<C, true, true>(m, S, A, Kb, L PF_PASS, &gfac, nact > 0 ? G + L.mrow : P<TQ>(nullptr), keep_p ? G + L.pst : P<TQ>(nullptr), top, false,
+                                                     pst_hi, pst_store);
+      if (!keep_p || pst_first(N, top, pst_hi) == N - 1) pst_hi = keep_p ? pst_store : -1;   // a full factorisation rewrote every tile it keeps; a resumed one left those above untouched
       top = -1;
       PF_STOP(PF_FACTOR);
       if (!fok) { why = QPX_NUMERIC; return false; }
