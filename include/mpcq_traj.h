@@ -23,8 +23,16 @@ int mpcq_minsnap_estimate_times(const double* wp, int32_t n, double v_max, doubl
 /* minimum-snap polynomials for given times: positions fixed at the waypoints, v / a / jerk continuous at interior
  * waypoints, zero at both ends */
 int mpcq_minsnap_solve(const double* wp, int32_t n, const double* T, double* pieces);
+/* the same linear solve with the cost on another derivative: 4 snap (= mpcq_minsnap_solve), 3 jerk (what the reference's genTrajectory is
+ * built with), 2 acceleration -- PolynomialOptimization<8>::solveLinear of mav_trajectory_generation */
+int mpcq_minsnap_solve_order(const double* wp, int32_t n, const double* T, int32_t derivative_to_optimize, double* pieces);
+/* the linear stage of the reference's generator as published: estimateSegmentTimes (Nfabian, constant 6.5) + solveLinear, no scaling onto
+ * the limits (the binary's nonlinear stage, an early-stopped Subplex run, is not reproducible: DESIGN.md section 6.1) */
+int mpcq_minsnap_linear(const double* wp, int32_t n, double v_max, double a_max, int32_t derivative_to_optimize, double* pieces);
 /* estimate + solve + uniform time scaling until the sampled peak speed / acceleration meet v_max / a_max */
 int mpcq_minsnap_generate(const double* wp, int32_t n, double v_max, double a_max, double* pieces);
+/* ... with the cost on derivative_to_optimize (mpcq_minsnap_generate = 4) */
+int mpcq_minsnap_generate_order(const double* wp, int32_t n, double v_max, double a_max, int32_t derivative_to_optimize, double* pieces);
 /* pieces -> sampled 13-state reference x [cap,13] every dt (save_evals_csv + load_trajectory, TrajectoryGenerator.py:208-244:
  * 6-decimal rounding, q = [1,0,0,0], rates 0); returns the number of rows or -1 (cap too small / bad arguments) */
 int mpcq_minsnap_sample(const double* pieces, int32_t nseg, double dt, double* x, int32_t cap);

@@ -92,7 +92,7 @@ void segment_cost(double T, double M[2 * ND][2 * ND], double Ainv[NC][NC], int o
 }
 
 // one axis: positions p[0..n-1] at the vertices, segment times T[0..n-2] -> coefficients coef[seg][8]
-bool solve_axis(const double* p, int n, const double* T, double* coef) {
+bool solve_axis(const double* p, int n, const double* T, double* coef, int order = 4) {
   const int ns = n - 1, nfree = 3 * (n - 2);
   std::vector<double> R((size_t)nfree * nfree, 0.0), rhs(nfree, 0.0);
   std::vector<std::vector<double>> Ainvs(ns, std::vector<double>(NC * NC));
@@ -101,7 +101,7 @@ bool solve_axis(const double* p, int n, const double* T, double* coef) {
   auto fixed_val = [&](int vertex, int r) { return r == 0 ? p[vertex] : 0.0; };
   for (int s = 0; s < ns; ++s) {
     double M[2 * ND][2 * ND], Ai[NC][NC];
-    segment_cost(T[s], M, Ai);
+    segment_cost(T[s], M, Ai, order);
     for (int i = 0; i < NC; ++i)
       for (int j = 0; j < NC; ++j) Ainvs[s][i * NC + j] = Ai[i][j];
     for (int a = 0; a < 2 * ND; ++a) {
@@ -156,6 +156,9 @@ void limits(const double* coef, const double* T, int ns, double dt, double* vmax
 
 extern "C" {
 
+int mpcq_minsnap_solve_order(const double* wp, int32_t n, const double* T, int32_t derivative_to_optimize, double* pieces);
+int mpcq_minsnap_generate_order(const double* wp, int32_t n, double v_max, double a_max, int32_t derivative_to_optimize, double* pieces);
+
 // Segment-time estimate from distance and the limits (velocity ramp: t = 2 d / v_max (1 + 6.5 v_max / a_max exp(-2 d / v_max))).
 int mpcq_minsnap_estimate_times(const double* wp, int32_t n, double v_max, double a_max, double* T) {
   if (!wp || !T || n < 2 || !(v_max > 0) || !(a_max > 0)) return -1;
@@ -170,8 +173,15 @@ int mpcq_minsnap_estimate_times(const double* wp, int32_t n, double v_max, doubl
 
 // Minimum-snap polynomials for given segment times.  wp [n,3], T [n-1] -> pieces [n-1, 33] in the reference's CSV row
 // layout (duration, x^0..x^7, y^0..y^7, z^0..z^7, yaw^0..yaw^7; yaw = 0).
-int mpcq_minsnap_solve(const double* wp, int32_t n, const double* T, double* pieces) {
-  if (!wp || !T || !pieces || n < 2) return -1;
+int mpcq_minsnap_solve(const double* wp, int32_t n, const double* T, double* pieces) { return mpcq_minsnap_solve_order(wp, n, T, 4, pieces); }
+
+// The same linear solve for the derivative the cost penalises: 4 = snap, 3 = jerk (what the reference's binary is built with:
+// mav_trajectory_generation::PolynomialOptimizationNonLinear<8>, derivative_to_optimize = JERK -- DESIGN.md section 6.1), 2 = acceleration.
+// This is PolynomialOptimization<8>::solveLinear of that library (Richter, Bry, Roy 2013; Burri et al. 2015): vertices made with
+// makeStartOrEnd(position, derivative_to_optimize) at both ends (derivatives 1..3 zero), position-only in between, the free vertex
+// derivatives from d_P = -R_PP^-1 R_FP^T d_F -- solve_axis above.
+int mpcq_minsnap_solve_order(const double* wp, int32_t n, const double* T, int32_t derivative_to_optimize, double* pieces) {
+  if (!wp || !T || !pieces || n < 2 || derivative_to_optimize < 2 || derivative_to_optimize > 4) return -1;
   const int ns = n - 1;
   for (int s = 0; s < ns; ++s)
     if (!(T[s] > 0)) return -1;
@@ -182,23 +192,37 @@ int mpcq_minsnap_solve(const double* wp, int32_t n, const double* T, double* pie
   }
   for (int ax = 0; ax < 3; ++ax) {
     for (int v = 0; v < n; ++v) p[v] = wp[v * 3 + ax];
-    if (!solve_axis(p.data(), n, T, c.data())) return -2;
+    if (!solve_axis(p.data(), n, T, c.data(), derivative_to_optimize)) return -2;
     for (int s = 0; s < ns; ++s)
       for (int i = 0; i < NC; ++i) pieces[(size_t)s * 33 + 1 + ax * NC + i] = c[(size_t)s * NC + i];
   }
   return 0;
 }
 
+// The LINEAR stage of the reference's generator, as published: segment times from estimateSegmentTimes(vertices, v_max, a_max) =
+// estimateSegmentTimesNfabian with its constant 6.5 (mpcq_minsnap_estimate_times), then the linear solve for derivative_to_optimize.
+// The binary continues from exactly this point with nlopt's Subplex over times and free derivatives, stopped early at loose
+// tolerances -- that part is not reproducible; this part is, and tests/test_minsnap.py documents how far it
+// is from the logged references per waypoint file.  No scaling onto the limits: peak speed / acceleration are what they are.
+int mpcq_minsnap_linear(const double* wp, int32_t n, double v_max, double a_max, int32_t derivative_to_optimize, double* pieces) {
+  if (n < 2) return -1;
+  std::vector<double> T(n - 1);
+  if (mpcq_minsnap_estimate_times(wp, n, v_max, a_max, T.data())) return -1;
+  return mpcq_minsnap_solve_order(wp, n, T.data(), derivative_to_optimize, pieces);
+}
+
 // Full generator: estimate the times, solve, then scale all times by one factor (bisection) so that the sampled peak
 // speed / acceleration are within v_max / a_max with the tighter of the two limits reached.  pieces [n-1, 33].
-int mpcq_minsnap_generate(const double* wp, int32_t n, double v_max, double a_max, double* pieces) {
-  if (n < 2) return -1;
+int mpcq_minsnap_generate(const double* wp, int32_t n, double v_max, double a_max, double* pieces) { return mpcq_minsnap_generate_order(wp, n, v_max, a_max, 4, pieces); }
+// ... with the cost on derivative_to_optimize (3: the jerk cost of the reference's binary, on the time proportions of its own estimate)
+int mpcq_minsnap_generate_order(const double* wp, int32_t n, double v_max, double a_max, int32_t derivative_to_optimize, double* pieces) {
+  if (n < 2 || derivative_to_optimize < 2 || derivative_to_optimize > 4) return -1;
   const int ns = n - 1;
   std::vector<double> T0(ns), T(ns), coef((size_t)ns * 4 * NC);
   if (mpcq_minsnap_estimate_times(wp, n, v_max, a_max, T0.data())) return -1;
   auto violation = [&](double scale) {   // > 1: over a limit
     for (int s = 0; s < ns; ++s) T[s] = T0[s] * scale;
-    if (mpcq_minsnap_solve(wp, n, T.data(), pieces)) return 1e30;
+    if (mpcq_minsnap_solve_order(wp, n, T.data(), derivative_to_optimize, pieces)) return 1e30;
     for (int s = 0; s < ns; ++s)
       for (int ax = 0; ax < 4; ++ax) std::memcpy(&coef[((size_t)s * 4 + ax) * NC], &pieces[(size_t)s * 33 + 1 + ax * NC], NC * sizeof(double));
     double vm, am;

@@ -109,7 +109,10 @@ def _traj_lib():
         dp = ctypes.POINTER(ctypes.c_double)
         lib.mpcq_minsnap_estimate_times.argtypes = [dp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, dp]
         lib.mpcq_minsnap_solve.argtypes = [dp, ctypes.c_int32, dp, dp]
+        lib.mpcq_minsnap_solve_order.argtypes = [dp, ctypes.c_int32, dp, ctypes.c_int32, dp]
+        lib.mpcq_minsnap_linear.argtypes = [dp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32, dp]
         lib.mpcq_minsnap_generate.argtypes = [dp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, dp]
+        lib.mpcq_minsnap_generate_order.argtypes = [dp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32, dp]
         lib.mpcq_minsnap_write_csv.argtypes = [ctypes.c_char_p, dp, ctypes.c_int32]
         lib.mpcq_minsnap_sample.argtypes = [dp, ctypes.c_int32, ctypes.c_double, dp, ctypes.c_int32]
         _TRAJ_LIB = lib
@@ -137,6 +140,38 @@ def minsnap_solve(waypoints, times):
     rc = _traj_lib().mpcq_minsnap_solve(_dptr(wp), len(wp), _dptr(T), _dptr(pieces))
     if rc:
         raise ValueError(f"mpcq_minsnap_solve failed ({rc})")
+    return pieces
+
+
+def minsnap_solve_order(waypoints, times, derivative_to_optimize):
+    """The linear solve with the cost on derivative 4 (snap), 3 (jerk: the reference's binary) or 2 (acceleration)."""
+    wp = np.ascontiguousarray(waypoints, dtype=np.float64).reshape(-1, 3)
+    T = np.ascontiguousarray(times, dtype=np.float64)
+    pieces = np.zeros((len(wp) - 1, 33))
+    rc = _traj_lib().mpcq_minsnap_solve_order(_dptr(wp), len(wp), _dptr(T), int(derivative_to_optimize), _dptr(pieces))
+    if rc:
+        raise ValueError(f"mpcq_minsnap_solve_order failed ({rc})")
+    return pieces
+
+
+def reference_linear_stage(waypoints, v_max, a_max, derivative_to_optimize=3):
+    """The linear stage of the reference's genTrajectory as published (mav_trajectory_generation): estimateSegmentTimes with the
+    constant 6.5, then PolynomialOptimization<8>::solveLinear for derivative_to_optimize (3 = jerk).  pieces [n - 1, 33]."""
+    wp = np.ascontiguousarray(waypoints, dtype=np.float64).reshape(-1, 3)
+    pieces = np.zeros((len(wp) - 1, 33))
+    rc = _traj_lib().mpcq_minsnap_linear(_dptr(wp), len(wp), float(v_max), float(a_max), int(derivative_to_optimize), _dptr(pieces))
+    if rc:
+        raise ValueError(f"mpcq_minsnap_linear failed ({rc})")
+    return pieces
+
+
+def minsnap_pieces_order(waypoints, v_max, a_max, derivative_to_optimize):
+    """minsnap_pieces with the cost on another derivative (3 = the jerk cost of the reference's binary)."""
+    wp = np.ascontiguousarray(waypoints, dtype=np.float64).reshape(-1, 3)
+    pieces = np.zeros((len(wp) - 1, 33))
+    rc = _traj_lib().mpcq_minsnap_generate_order(_dptr(wp), len(wp), float(v_max), float(a_max), int(derivative_to_optimize), _dptr(pieces))
+    if rc:
+        raise ValueError(f"mpcq_minsnap_generate_order failed ({rc})")
     return pieces
 
 
