@@ -83,10 +83,10 @@ typedef struct mpcq_tuning {
   int32_t stage_mem;    /* layout of the per-instance working set: 0 automatic, 1 all LDS, 2 per-stage records in global memory (L2),
                            3 compact (since 0.4: Riccati gains in global memory as well, <= 256 registers: more instances per CU) */
   int32_t generic_kernel; /* 1: the any-shape kernel instance even where a shape-specialised one exists */
-  double pin_ratio;     /* interior point -> working set: pinned where multiplier > pin_ratio x slack, (0, 1e3] (default 0.2 f64 / 1 f32) */
+  double pin_ratio;     /* interior point -> working set: pinned where multiplier > pin_ratio x slack, (0, 1e3] (default 0.2) */
   double ipm_mu0;       /* complementarity of the interior start in units of the gradient scale, [1e-12, 1] (default 1e-4) */
   double ipm_margin;    /* interior start: distance from the bounds in units of their width, (0, 0.5) (default 0.1) */
-  double ipm_tol;       /* interior point -> active-set hand-over tolerance, [qp_tol, 1e-1] (default 1e-6 f64 / 1e-4 f32) */
+  double ipm_tol;       /* interior point -> active-set hand-over tolerance, [qp_tol, 1e-1] (default 1e-6 f64 / 1e-5 f32) */
   /* ---- since 0.4 */
   int32_t block_order;  /* launch order of a lockstep period: 0 automatic (quadrotors predicted expensive first when the batch exceeds
                            what the device holds at once), 1 never (workgroup p = quadrotor p), 2 always.  Results do not depend on it. */

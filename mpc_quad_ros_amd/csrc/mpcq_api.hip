@@ -302,7 +302,11 @@ struct EngineT : mpcq_engine {
     auto ienv = [&](const char* name, int v) { const char* t = env ? getenv(name) : nullptr; return t ? atoi(t) : v; };
     auto fenv = [&](const char* name, double v) { const char* t = env ? getenv(name) : nullptr; return t ? atof(t) : v; };
     auto off = [](int v) { return v < 0 ? 0 : v; };   // -1 = "never": the kernel's encoding is 0 (flip_max: -1)
-    m.ipm_tol = (T)fenv("MPCQ_IPM_TOL", tu.ipm_tol > 0 ? tu.ipm_tol : (f32 ? 1e-4 : 1e-6));
+    // (float: 1e-5.  The mixed-precision method judges multipliers on double residuals, so a hand-over as tight as fp64's pays -- bench
+    //  workload, 200 lockstep periods: 1e-4 / pin_ratio 1 2.70 M steps/s, 1e-5 / 0.2 2.89 M, 1e-6 / 0.2 2.94 M -- but below 1e-5 the float
+    //  interior point itself loses a stage Hessian's definiteness now and then at N = 50 (the active-set method then takes over from its
+    //  last iterate, solve_qp): 1e-5 keeps it out of that regime)
+    m.ipm_tol = (T)fenv("MPCQ_IPM_TOL", tu.ipm_tol > 0 ? tu.ipm_tol : (f32 ? 1e-5 : 1e-6));
     // fp64 passes alternate between a multiplier check and an affine solve: twice the count of fp32's
     m.polish_max = ienv("MPCQ_POLISH_MAX", tu.polish_max ? off(tu.polish_max) : (f32 ? 12 : 16));
     // passes of the warm active-set attempt before falling back to the interior point (fp64: one factorisation each, an
@@ -312,9 +316,9 @@ struct EngineT : mpcq_engine {
     m.warm_max = ienv("MPCQ_WARM_MAX", tu.warm_max > 0 ? tu.warm_max : 12);
     m.warm_retry = ienv("MPCQ_WARM_RETRY", tu.warm_retry > 0 ? tu.warm_retry : 1);
     m.ipm_margin = (T)fenv("MPCQ_IPM_MARGIN", tu.ipm_margin > 0 ? tu.ipm_margin : 0.1);
-    // hand-over from the interior point: an input joins the working set when its multiplier exceeds pin_ratio x its slack.
-    // fp32 keeps 1: its multiplier sign test cannot tell a wrongly pinned weakly active input from a rightly pinned one
-    m.pin_ratio = (T)fenv("MPCQ_PIN_RATIO", tu.pin_ratio > 0 ? tu.pin_ratio : (f32 ? 1.0 : 0.2));
+    // hand-over from the interior point: an input joins the working set when its multiplier exceeds pin_ratio x its slack
+    // (weakly active ones are pinned at once, wrongly pinned ones leave through the multiplier check of the same pass)
+    m.pin_ratio = (T)fenv("MPCQ_PIN_RATIO", tu.pin_ratio > 0 ? tu.pin_ratio : 0.2);
     // complementarity of the interior start in units of the gradient scale: the start is the previous solution pushed inside
     // the box, i.e. close to the new optimum, a small value makes it a warm start
     m.ipm_mu0 = (T)fenv("MPCQ_IPM_MU0", tu.ipm_mu0 > 0 ? tu.ipm_mu0 : 1e-4);

@@ -2225,11 +2225,17 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
   int nact = 1, careful = 0;
   double gF_prev = -1, dz_prev = 0;   // residual and correction of the previous refinement step on this working set (< 0: none)
   auto set_dx0 = [&]() { if (tid < VS) D[L.dxd + tid] = tid < NX ? D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)] : 0.0; };   // dx_0 = x_meas - X_0, in double
-  for (passes = 0; passes < max_passes; ++passes) {
+  // max_passes budgets FACTORISATIONS (as in the fp64 method, where a pass is one): a refinement step reuses the factorisation at hand and is
+  // not charged -- a warm solve without a change of the working set is two trips of this loop and one factorisation.  (Charging trips made
+  // every solve behind a fallback fail its one-pass retry and fall back again, period after period: 8 % of the quadrotor-steps.)
+  int nfac = 0;
+  const int trip_cap = 3 * max_passes + 4;
+  for (passes = 0; passes < trip_cap; ++passes) {
     const bool aff = warm && passes == 0;
     bool corrected = false;
     double gF = 0, vmax = 0;
     if (aff) {
+      nfac += 1;
       // Warm start from z = 0 with every pinned input at a bound of exactly 0: the minimiser on the working set is the solution of the
       // affine LQ problem itself (gaps c_i, gradients q_i, r_i in the recursion): one factorisation and one forward sweep.
       int na = 0;
@@ -2298,6 +2304,8 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
       released = rel_now;
       if (rel_now) gF_prev = -1;
       if (refactor) {
+        if (nfac >= max_passes) break;   // out of budget (why = QPX_BUDGET)
+        nfac += 1;
         for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
         __syncthreads();
         PF_START();
@@ -2456,6 +2464,25 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
           }
           passes += p2;
         }
+      }
+    }
+  }
+  if constexpr (sizeof(TQ) == 4) {
+    // float: an interior point that broke down before its tolerance (a stage Hessian lost definiteness in float -- seen at N = 50 with the
+    // complementarity below 1e-5 --, or the iteration cap) leaves a feasible interior iterate: the active-set method takes over from it
+    if ((st == 4 || st == 2) && need_roll) {
+      int finite = 1;
+      for (int i = tid; i < nv; i += 64) { const TQ v = S[L.z + i]; if (!(tabs(v) < TQ(1e30)) || !(S[L.sl + i] > TQ(0)) || !(S[L.su + i] > TQ(0))) finite = 0; }
+      if (wave_min(finite)) {
+        for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
+        __syncthreads();
+        int p2 = 0, why3 = 0;
+        if (active_set(gm, p2, false, 2 * m.polish_max, why3, true)) { need_roll = false; st = 0; }
+        else {
+          for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
+          __syncthreads();
+        }
+        passes += p2;
       }
     }
   }

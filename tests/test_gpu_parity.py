@@ -386,7 +386,11 @@ def test_matrix_cores_off_build_is_bit_identical():
     if not os.path.exists(nomfma):
         pytest.skip("libmpcq_nomfma.so not built (make -C mpc_quad_ros_amd/csrc variant NAME=nomfma ...)")
     from mpc_quad_ros_amd import _lib
-    if _lib.load(nomfma).mpcq_version() != _lib.load().mpcq_version():      # the version string carries the hash of the sources
+    try:
+        stale = _lib.load(nomfma).mpcq_version() != _lib.load().mpcq_version()      # the version string carries the hash of the sources
+    except AttributeError:                                                           # an entry point this header declares is missing: older still
+        stale = True
+    if stale:
         pytest.skip("libmpcq_nomfma.so was built from other sources than libmpcq.so (rebuild the variant)")
     B, N, nb, K = 12, 50, 50, 12
     traj, lens = swarm_trajectories(21, 0, B)

@@ -20,7 +20,8 @@ SETTINGS = [{}, {"ipm_tol": 3e-6}, {"ipm_tol": 1e-5}, {"ipm_tol": 1e-4}, {"ipm_t
 if os.environ.get("SWEEP"):
     SETTINGS = json.loads(os.environ["SWEEP"])
 for tune in SETTINGS:
-    e = Engine(EngineConfig(batch=B, N=20, quad=hummingbird(), nb=10, basis=rgp_basis_linspace(12.0, 10), tune=tune or None))
+    e = Engine(EngineConfig(batch=B, N=20, quad=hummingbird(), nb=10, basis=rgp_basis_linspace(12.0, 10), tune=tune or None,
+                            precision=1 if os.environ.get("SWEEP_F32") else 0))
     e.set_trajectories(*refs); e.sim_reset(np.tile(bench.X0, (B, 1)))
     e.sim_run(600, 2, 5e-3)
     e.sim_steps(5, 2, 5e-3); e.synchronize()
