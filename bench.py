@@ -578,15 +578,17 @@ def main():
         sw_roof = {"bound": "hbm", "achieved": sw_bytes / (leg["kernel_avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                    "algorithmic_bytes_per_launch": sw_bytes}
         sw_roof["frac"] = sw_roof["achieved"] / HBM_PEAK_GBS
-        try:
-            with open(os.path.join(ROOT, "profiles", "r4_pmc_traffic_swarm_b8192.json")) as fh:
-                tsw = json.load(fh)
+        import glob as _glob
+        for tf in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_swarm_b8192.json"))):      # the profile taken on THIS build, if any
+            try:
+                with open(tf) as fh:
+                    tsw = json.load(fh)
+            except (OSError, ValueError):
+                continue
             if tsw.get("source_sha16") == kernel_source_sha16():
                 sw_roof["traffic"] = tsw["hbm_bytes_per_launch"]
                 sw_roof["traffic_frac_of_peak"] = tsw["hbm_bytes_per_launch"] / (leg["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                sw_roof["traffic_source"] = "profiles/r4_pmc_traffic_swarm_b8192.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/large_batch.py 8192 20 10, same build)"
-        except (OSError, ValueError):
-            pass
+                sw_roof["traffic_source"] = f"profiles/{os.path.basename(tf)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/large_batch.py 8192 20 10, same build)"
         swarm_out["roofline"] = sw_roof
         swarm_out.update({"config": f"BASELINE configs[3]: swarm of {SWARM * world} quadrotors, {SWARM} per GPU over {world} GPU(s)"
                                     + (" (= the per-rank shard of the 65 536-quadrotor swarm)" if world == 1 else ""),

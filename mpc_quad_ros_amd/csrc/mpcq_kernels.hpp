@@ -955,14 +955,17 @@ __device__ inline void shoot_sens_t(const M& m, P<TR> S, P<TR> A, const Lds& L, 
 
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
 MPCQ_PHASE void shoot_sens(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L) {
-  // The float instances run THIS pass in float: what the double integration of shoot_states buys is the gap c_i (the residual of the
-  // dynamics, which the QP solution follows one to one); the sensitivities only shape the QP's curvature, and computed in float from the
-  // double pass's records they leave the control deviation where the double version does (measured on the saturating references that
-  // exposed the float state pass: 3e-7 either way).  -DMPCQ_MIXED_SENS64: in double as well.
-#ifdef MPCQ_MIXED_SENS64
-  shoot_sens_t<C, typename ShootT<TQ>::T, TQ>(m, S, A, L, cN<C>(m));
-#else
+  // The float instances run this pass in double as well (records rounded to float once).  What the double integration buys first is the
+  // gap c_i of shoot_states (the residual of the dynamics, which the QP solution follows one to one: 7e-4 -> 3e-7 on a saturated quadrotor);
+  // the sensitivities shape the QP's curvature, and computed in float they cost another factor 3-5 where the horizon is long and the inputs
+  // idle near zero (N = 50, bench workload: worst deviation 9.5e-6 against 2.0e-6 of full thrust).  What is left is the float STORAGE of
+  // AB'' (6e-8 relative): keeping what the float gaps and cost gradients drop of their double values as a second float, read by the
+  // double sweeps only, was measured and changed nothing (7.8e-5 against 9.2e-5 of an idling quadrotor's own largest control) at 5-10 % of
+  // the speed.  -DMPCQ_MIXED_SENS32: this pass in float (2-3 % faster).
+#ifdef MPCQ_MIXED_SENS32
   shoot_sens_t<C, TQ, TQ>(m, S, A, L, cN<C>(m));
+#else
+  shoot_sens_t<C, typename ShootT<TQ>::T, TQ>(m, S, A, L, cN<C>(m));
 #endif
 }
 
@@ -2218,8 +2221,10 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
     }
   }
   double tolm = 1e-12 * (double)gm;   // multiplier sign test: the multipliers come from double residuals (the fp64 method: 64 eps gm = 7e-15 gm)
-  const double tolb = 16 * (double)m.eps;   // bound proximity of a pin (bounds are O(1))
-  const double tol_c = MPCQ_MIXED_TOLC, tol_z = 1e-6;
+  // bound proximity of a pin and what a refinement may leave behind, in units of full thrust: the iterate is double, so neither needs the
+  // float-sized 1e-6 of the first version
+  const double tolb = 1e-9;
+  const double tol_c = MPCQ_MIXED_TOLC, tol_z = 1e-7;
   bool refactor = true, settled = false, full = false, released = false;
   bool need_roll = true;              // D[L.dxd] is not the state trajectory of D[L.zd] (z was changed outside a sweep)
   int nact = 1, careful = 0;
