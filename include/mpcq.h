@@ -86,7 +86,7 @@ typedef struct mpcq_tuning {
   double pin_ratio;     /* interior point -> working set: pinned where multiplier > pin_ratio x slack, (0, 1e3] (default 0.2) */
   double ipm_mu0;       /* complementarity of the interior start in units of the gradient scale, [1e-12, 1] (default 1e-4) */
   double ipm_margin;    /* interior start: distance from the bounds in units of their width, (0, 0.5) (default 0.1) */
-  double ipm_tol;       /* interior point -> active-set hand-over tolerance, [qp_tol, 1e-1] (default 1e-6 f64 / 1e-5 f32) */
+  double ipm_tol;       /* interior point -> active-set hand-over tolerance, [qp_tol, 1e-1] (default 1e-6 f64 / 1e-5 f32; f32: not below 1e-5) */
   /* ---- since 0.4 */
   int32_t block_order;  /* launch order of a lockstep period: 0 automatic (quadrotors predicted expensive first when the batch exceeds
                            what the device holds at once), 1 never (workgroup p = quadrotor p), 2 always.  Results do not depend on it. */
@@ -108,7 +108,8 @@ typedef struct mpcq_config {
   double rotor_drag[3], aero_drag; /* plant only (src/quad.py:79-89); unused by the controller path */
   double W[17], W_e[13];           /* diagonal LS weights; stage cost is scaled by T/N (acados) */
   double u_lb[4], u_ub[4], u_ref[4];
-  double qp_tol;      /* KKT tolerance of the box-QP solve; 0 = default for the precision */
+  double qp_tol;      /* KKT tolerance of the interior point's last resort; 0 = default for the precision (1e-11 f64, 1e-5 f32: smaller values
+                         are raised to 1e-5 there, the f32 answer is refined against fp64 residuals behind the interior point) */
   const double* basis;   /* [3*nb] basis vectors X per axis */
   const double* theta;   /* [3*3] per axis: L, sigma_f, sigma_n */
   int32_t device;        /* HIP device ordinal */

@@ -286,7 +286,11 @@ struct EngineT : mpcq_engine {
     m.N = N; m.nb = nb; m.skip = c.skip; m.Tmax = 0; m.B = B;
     const bool f32 = sizeof(T) == 4;
     m.qp_max_iter = c.qp_max_iter > 0 ? c.qp_max_iter : 60;
-    m.qp_tol = (T)(c.qp_tol > 0 ? c.qp_tol : (f32 ? 2e-6 : 1e-11));
+    // (float: the interior point is not asked for more than 1e-5 -- below that its complementarity collapses while the float residual
+    //  stalls, and a stage Hessian loses definiteness or the iterate its finiteness; the answer's accuracy comes from the refinement
+    //  against fp64 residuals behind it, not from the interior point's own tolerance.  Smaller values are raised to 1e-5.)
+    m.qp_tol = (T)(c.qp_tol > 0 ? c.qp_tol : (f32 ? 1e-5 : 1e-11));
+    if (f32 && m.qp_tol < (T)1e-5) m.qp_tol = (T)1e-5;
     m.eps = f32 ? (T)6e-8 : (T)1.1e-16;
     // ---- solver tuning: mpcq_config.tune (0 = default), validated by mpcq_create_sized; with MPCQ_TUNING=1 the environment
     // overrides a field (measurement scripts).  How the defaults were measured: DESIGN.md section 3.3.

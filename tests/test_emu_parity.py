@@ -172,6 +172,23 @@ def test_emu_f32_qp_mode_within_budget():
     assert pc.case_swarm_closed_loop(make, B=2, N=20, nb=10, K=10, precision=1) < 1e-4
 
 
+def test_emu_f32_saturating_references_through_the_interior_point():
+    """The mixed-precision path where a float-only solve is 1e-2 off (round 4): infeasible references, inputs saturated over most of the
+    horizon, nearly every solve through the float interior point, the active-set method with fp64 residuals behind it (including the
+    last-resort run behind the interior point's final iterations).  Every solve within the 1e-4 budget, none failed, status 0."""
+    worst, hist, failed = pc.case_saturating_references(make, B=2, K=14, precision=1)
+    print("f32 saturating references: worst", worst, "passes", dict(sorted(hist.items())))
+    assert failed == 0 and worst < pc.TOL_TF[1]
+    from mpc_quad_ros_amd.engine import qp_fallback
+    assert sum(n for v, n in hist.items() if qp_fallback(v)) >= 8
+
+
+def test_emu_f32_long_horizon_cold_start_in_flight():
+    """N = 50 / nb = 50 in f32, started in flight with a cold iterate (interior-point solves, many pins at once): teacher-forced, every
+    solve within the budget.  (The GPU test runs 64 quadrotors x 60 periods of this; here 2 x 3 on the emulator.)"""
+    assert pc.case_swarm_closed_loop(make, B=2, N=50, nb=50, K=3, precision=1, start=200) < pc.TOL_TF[1]
+
+
 def test_emu_facade_mirrors_quad_optimizer(lib=EMU):
     from mpc_quad_ros_amd.quad_opt import quad_optimizer
     from mpc_quad_ros_amd.params import hummingbird, rgp_basis_linspace
