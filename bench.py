@@ -66,7 +66,7 @@ def latency_roofline(e, n_sub, N, launches=20):
             fl = json.load(fh)
     except (OSError, ValueError):
         return None
-    floor, got, slow_fac = [], [], []
+    floor, got, slow_fac, slow_ipm = [], [], [], []
     for _ in range(launches):
         e.sim_steps(1, n_sub, 5e-3)
         kt, _kl = e.get_kernel_time()
@@ -74,9 +74,13 @@ def latency_roofline(e, n_sub, N, launches=20):
         chain_ns = (fac * fl["factor_stage_chain_ns"] + swp * fl["sweep_stage_chain_ns"]) * N
         floor.append(float(chain_ns.max()) * 1e-6 + NONQP_CHAIN_US * 1e-3)
         got.append(1e3 * kt)
-        slow_fac.append(int(fac[np.argmax(chain_ns)]))
+        b = int(np.argmax(chain_ns))
+        slow_fac.append(int(fac[b]))
+        # interior-point iterations of that solve: a fallback solve executes 2 it + 2 (+1) more sweeps than factorisations (solve_qp's work count)
+        slow_ipm.append(max(0, (int(swp[b]) - int(fac[b]) - 2) // 2) if qp_fallback(e.get_qp_iter()[b]) else 0)
     return {"bound": "dependent-chain latency of the slowest quadrotor of a launch", "floor_ms": float(np.mean(floor)), "achieved_ms": float(np.mean(got)),
             "frac": float(np.mean(floor) / np.mean(got)), "launches": launches, "slowest_quad_factorisations_mean": float(np.mean(slow_fac)),
+            "slowest_quad_interior_point_iterations_mean": float(np.mean(slow_ipm)),
             "factor_stage_chain_ns": fl["factor_stage_chain_ns"], "sweep_stage_chain_ns": fl["sweep_stage_chain_ns"], "non_qp_phases_us_measured": NONQP_CHAIN_US,
             "note": "floor = chain latencies measured in isolation (registers only, one wavefront per SIMD); the product's stage additionally loads its "
                     "operands, hands rows over through LDS, stores gains / cost-to-go and carries ~4x the instructions of the bare chain"}

@@ -71,7 +71,8 @@ typedef enum mpcq_status {
  * precision; validated by mpcq_create (MPCQ_ERR_INVALID outside the stated range).  The defaults were measured on two
  * workloads; results do not depend on them beyond rounding.  With MPCQ_TUNING=1 in the
  * environment, MPCQ_WARM_MAX, MPCQ_WARM_RETRY, MPCQ_FLIP_MAX, MPCQ_ABORT_PINS, MPCQ_ABORT_WRONG, MPCQ_POLISH_MAX,
- * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global|compact, MPCQ_GENERIC=1, MPCQ_BLOCK_ORDER override
+ * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global|compact, MPCQ_GENERIC=1, MPCQ_BLOCK_ORDER,
+ * MPCQ_SPLIT_PLANT=0|1 (the plant update between two lockstep periods as its own launch), MPCQ_KEV_STRIDE, MPCQ_VERBOSE=1 override
  * the corresponding field (measurement scripts only; without MPCQ_TUNING=1 the environment is not consulted). */
 typedef struct mpcq_tuning {
   int32_t warm_max;     /* passes of the warm active-set attempt, 1..64 (default 12; 6 in fp64 before round 4) */
