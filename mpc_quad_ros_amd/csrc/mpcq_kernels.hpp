@@ -1526,7 +1526,10 @@ MPCQ_COLD int ipm_run_regs(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, co
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) printf("  ipm it %2d: |r_d|/gm %.3e  mu %.3e  (tol %.1e)\n", it, (double)(rdm / gm), (double)mu, (double)tol);
 #endif
-    if (rdm <= tol * gm && mu <= tol) { status = 0; break; }
+    // (float: the dual residual comes from a float gradient sweep whose own noise is ~1e-4 of the gradient scale on ill-conditioned
+    //  instances -- asked for less, the iteration oscillates around that floor until its cap (1 solve in 3e5 at N = 50); what the
+    //  active-set method behind needs from here is the complementarity, the residual it evaluates itself in double)
+    if (rdm <= (sizeof(TQ) == 4 ? tmax(tol, TQ(3e-4)) : tol) * gm && mu <= tol) { status = 0; break; }
     // predictor: (H + Sigma) dza = -grad
     TQ rsl[R], rsu[R];
 #pragma unroll
@@ -1559,12 +1562,15 @@ MPCQ_COLD int ipm_run_regs(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, co
     mua = wave_sum(mua) / (2 * nv);
     TQ sigma = mua / mu;
     sigma = sigma * sigma * sigma;
+    // float: the centring target does not go below a tenth of the tolerance -- from a warm start the complementarity can collapse (x 0.1
+    // per iteration) while the residual lags, and at 1e-8 the float factorisation loses a stage Hessian's definiteness (1 solve in 1e6)
+    const TQ smu = sizeof(TQ) == 4 ? tmax(sigma * mu, TQ(0.1) * tol) : sigma * mu;
     // corrector rhs r = -rd + rcl/sl - rcu/su ; linear term rho = -r
     TQ rcl[R], rcu[R], rho[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      rcl[r] = -sl[r] * ll[r] + sigma * mu - da[r] * dla[r];
-      rcu[r] = -su[r] * lu[r] + sigma * mu + da[r] * dua[r];
+      rcl[r] = -sl[r] * ll[r] + smu - da[r] * dla[r];
+      rcu[r] = -su[r] * lu[r] + smu + da[r] * dua[r];
       const TQ rd = g[r] - ll[r] + lu[r];
       rho[r] = rd - rcl[r] * rsl[r] + rcu[r] * rsu[r];
       if (on[r]) S[L.rho + ix[r]] = rho[r];
@@ -1630,7 +1636,10 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const L
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) printf("  ipm it %2d: |r_d|/gm %.3e  mu %.3e  (tol %.1e)\n", it, (double)(rdm / gm), (double)mu, (double)tol);
 #endif
-    if (rdm <= tol * gm && mu <= tol) { status = 0; break; }
+    // (float: the dual residual comes from a float gradient sweep whose own noise is ~1e-4 of the gradient scale on ill-conditioned
+    //  instances -- asked for less, the iteration oscillates around that floor until its cap (1 solve in 3e5 at N = 50); what the
+    //  active-set method behind needs from here is the complementarity, the residual it evaluates itself in double)
+    if (rdm <= (sizeof(TQ) == 4 ? tmax(tol, TQ(3e-4)) : tol) * gm && mu <= tol) { status = 0; break; }
     // predictor: (H + Sigma) dza = -grad
     for (int i = tid; i < nv; i += 64) S[L.rho + i] = S[L.grad + GI(i)];
     __syncthreads();
@@ -1661,13 +1670,14 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const L
     mua = wave_sum(mua) / (2 * nv);
     TQ sigma = mua / mu;
     sigma = sigma * sigma * sigma;
+    const TQ smu = sizeof(TQ) == 4 ? tmax(sigma * mu, TQ(0.1) * tol) : sigma * mu;   // (see ipm_run_regs)
     // corrector rhs r = -rd + rcl/sl - rcu/su ; linear term rho = -r
     for (int i = tid; i < nv; i += 64) {
       const TQ d = S[L.dza + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
       const TQ rsl = trcp(sl), rsu = trcp(su);
       const TQ dl = -ll - ll * rsl * d, du = -lu + lu * rsu * d;
-      const TQ rcl = -sl * ll + sigma * mu - d * dl;
-      const TQ rcu = -su * lu + sigma * mu + d * du;
+      const TQ rcl = -sl * ll + smu - d * dl;
+      const TQ rcu = -su * lu + smu + d * du;
       const TQ rd = S[L.grad + GI(i)] - ll + lu;
       S[L.rho + i] = rd - rcl * rsl + rcu * rsu;
     }
@@ -1681,8 +1691,8 @@ MPCQ_COLD int ipm_run(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const L
       const TQ da = S[L.dza + i], d = S[L.dz + i], sl = S[L.sl + i], su = S[L.su + i], ll = S[L.ll + i], lu = S[L.lu + i];
       const TQ rsl = trcp(sl), rsu = trcp(su);
       const TQ dla = -ll - ll * rsl * da, dua = -lu + lu * rsu * da;
-      const TQ rcl = -sl * ll + sigma * mu - da * dla;
-      const TQ rcu = -su * lu + sigma * mu + da * dua;
+      const TQ rcl = -sl * ll + smu - da * dla;
+      const TQ rcu = -su * lu + smu + da * dua;
       const TQ dl = (rcl - ll * d) * rsl, du = (rcu + lu * d) * rsu;
       apinv = tmax(apinv, tmax(-d * rsl, d * rsu));
       adinv = tmax(adinv, tmax(-dl * trcp(ll), -du * trcp(lu)));
@@ -2230,6 +2240,35 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
   int nact = 1, careful = 0;
   double gF_prev = -1, dz_prev = 0;   // residual and correction of the previous refinement step on this working set (< 0: none)
   auto set_dx0 = [&]() { if (tid < VS) D[L.dxd + tid] = tid < NX ? D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)] : 0.0; };   // dx_0 = x_meas - X_0, in double
+  // Release of wrong-signed multipliers at a minimiser of the working set, by level of caution:
+  //   0  every wrong-signed one (the fast path: one pass settles what the other levels take several for);
+  //   1  per rotor only the worst one (the rule of the fp64 method: the multipliers of one rotor's run of saturated stages are strongly
+  //      coupled; input i belongs to rotor i & 3 = lane & 3), and every WEAK one with them (under 1e-4 of the gradient scale);
+  //   2  per rotor the worst one, only rotors whose worst is within 1.6x of the overall worst;
+  //   3  the worst one overall (the classical rule).
+  // The level rises when a release bounces (the freed inputs get pinned again) and when its Newton step is wild (below).  Thresholds and
+  // candidates both come from the float images of the multipliers in S[L.grad], so the worst one always passes its own threshold.
+  auto release = [&](const int level) {
+    float vr = 0;
+    for (int i = tid; i < nv; i += 64) {
+      const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
+      if (a != TQ(0)) vr = tmax(vr, a < 0 ? -g : g);
+    }
+    const float vall = wave_max(vr);
+    float rel_thr = level == 0 ? 0.0f : vall;
+    if (level == 1 || level == 2) {
+      const float w0 = wave_max((tid & 3) == 0 ? vr : 0.0f), w1 = wave_max((tid & 3) == 1 ? vr : 0.0f),
+                  w2 = wave_max((tid & 3) == 2 ? vr : 0.0f), w3 = wave_max((tid & 3) == 3 ? vr : 0.0f);
+      rel_thr = (tid & 3) == 0 ? w0 : ((tid & 3) == 1 ? w1 : ((tid & 3) == 2 ? w2 : w3));
+      if (level == 2) rel_thr = tmax(rel_thr, 0.625f * vall);
+    }
+    const float weak = level == 1 ? 1e-4f * gm : 0.0f;
+    for (int i = tid; i < nv; i += 64) {
+      const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
+      const float v = a < 0 ? -g : g;
+      if (a != TQ(0) && (double)v > tolm && (v >= rel_thr || v <= weak)) S[L.act + i] = 0;
+    }
+  };
   // max_passes budgets FACTORISATIONS (as in the fp64 method, where a pass is one): a refinement step reuses the factorisation at hand and is
   // not charged -- a warm solve without a change of the working set is two trips of this loop and one factorisation.  (Charging trips made
   // every solve behind a fallback fail its one-pass retry and fall back again, period after period: 8 % of the quadrotor-steps.)
@@ -2288,12 +2327,8 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
       bool rel_now = false;
       if (full) {   // the point minimises the QP on the working set up to the error under refinement: multipliers are meaningful
         if (vmax > tolm) {
-          const double rel_thr = careful == 0 ? 0.0 : (careful == 1 ? 0.25 * vmax : (careful == 2 ? 0.625 * vmax : vmax));
-          for (int i = tid; i < nv; i += 64) {
-            const TQ a = S[L.act + i];
-            const double g = (double)S[L.grad + GI(i)], v = a < 0 ? -g : g;
-            if (a != TQ(0) && v > tolm && v >= rel_thr) S[L.act + i] = 0;   // release wrong-signed multipliers
-          }
+          for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.act + i];   // the working set in front of the release (S[L.z] is free while zd is the iterate)
+          release(careful);
           refactor = true;
           rel_now = true;
           __syncthreads();
@@ -2321,6 +2356,22 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
       }
       PF_START(); riccati_forward64<C, false>(m, D, S, A, Kb, L PF_PASS); PF_STOP(PF_FWD);
       corrected = full && !rel_now;
+      // A release whose Newton step leaves the box by more than half its width is a cascade in the making (the step gets clipped, the
+      // violators pinned wholesale, the next multipliers are worse; seen at N = 50: 44 inputs pinned in one pass, the working set driven
+      // to 199 of 200): taken back -- the next trip of the loop re-evaluates the same point and releases one level more cautiously.
+      if (rel_now && careful < 3) {
+        float dmx = 0;
+        for (int i = tid; i < nv; i += 64)
+          if (S[L.act + i] == TQ(0)) dmx = tmax(dmx, tabs(S[L.dz + i]));
+        if (wave_max(dmx) > 0.5f) {
+          for (int i = tid; i < nv; i += 64) S[L.act + i] = S[L.z + i];
+          careful += 1;
+          refactor = true; need_roll = true;   // (the sweep taken back had moved the trajectory along)
+          released = false;
+          __syncthreads();
+          continue;
+        }
+      }
     }
     // full Newton step; if it leaves the box, clip and pin EVERY violator at once
     int viol = 0;
@@ -2385,13 +2436,7 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
   int it = 0, passes = 0, wpasses = 0, why = 0;
   TQ gm = 1;
   const P<TQ> Kb = C::GK ? G : S;   // where the gains live
-  // the active-set method of the precision: fp64 -- one affine solve per working set (polish); float -- the mixed-precision method
-  // (polish_mixed: float factorisation, iterate and residuals in double).  conv: 0 when its refinement did not converge.
-  int conv = 1;
-  auto active_set = [&](TQ g, int& np, const bool warm, const int cap, int& wy, const bool last_resort = false) -> bool {
-    if constexpr (sizeof(TQ) == 8) return polish<C>(m, S, A, G, L, g, np, warm, cap, wy PF_PASS);
-    else return polish_mixed<C>(m, D, S, A, Kb, L, g, np, warm, cap, wy, conv, last_resort PF_PASS);
-  };
+  static_assert(sizeof(TQ) == 8, "float instances solve their QP in solve_qp_mixed");
   // prev_iter: this quadrotor's previous return value (0: cold start).  Decimal fields (qp_iter of include/mpcq.h):
   //   passes + interior-point iterations | x 1000: the warm attempt was given up or skipped (fallback solve) |
   //   x 10000: flip mark | x 100000: why the warm attempt ended (QPX_*).
@@ -2406,23 +2451,14 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
   const int warm_cap = flipping ? 0 : ((prev_iter / 1000) % 10 != 0 ? m.warm_retry : m.warm_max);
   if (flipping) { wpasses = 1000; why = QPX_SKIPPED; }   // counts as a fallback solve
   if (prev_iter > 0 && warm_cap > 0) {
-    if (active_set(gm, wpasses, true, warm_cap, why)) {   // sets z = 0 and its own gradient scale
-      *status = conv ? 0 : 8;
+    if (polish<C>(m, S, A, G, L, gm, wpasses, true, warm_cap, why PF_PASS)) {   // sets z = 0 and its own gradient scale
+      *status = 0;
       *work = wpasses | (wpasses << 16);   // one (possibly resumed) factorisation and one forward sweep per pass
       return wpasses;
     }
     wpasses += 1000;
   }
   int st = 0;
-  // float: the refined solution's state trajectory D[L.dxd] shares its space with the float vectors dx | Dx; behind an active-set attempt
-  // that did not settle, dx_0 = x_meas - X_0 is put back in front of the float rollout
-  auto restore_dx0 = [&]() {
-    if constexpr (sizeof(TQ) == 4) {
-      if (tid < VS) S[L.dx + tid] = tid < NX ? (TQ)(D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)]) : TQ(0);
-      __syncthreads();
-    }
-  };
-  restore_dx0();
   // interior start
   for (int i = tid; i < nv; i += 64) {
     const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
@@ -2445,64 +2481,17 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
     int why2 = 0;
-    if (active_set(gm, passes, false, m.polish_max, why2)) need_roll = false;
+    if (polish<C>(m, S, A, G, L, gm, passes, false, m.polish_max, why2 PF_PASS)) need_roll = false;
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();
-      restore_dx0();
       PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
       PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
       st = ipm_run<C>(m, S, A, Kb, L, m.qp_tol, gm, it PF_PASS);
-      if constexpr (sizeof(TQ) == 4) {
-        // float: the interior point's own answer is good to ~sqrt(eps32) on weakly active inputs only.  Its working set at the final
-        // tolerance is (nearly) the optimal one: the active-set method once more from there, without the early exit, ends on the
-        // solution refined against fp64 residuals; only if that fails too is the interior point's answer taken -- and reported.
-        if (st == 0) {
-          for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
-          __syncthreads();
-          int p2 = 0, why3 = 0;
-          if (active_set(gm, p2, false, 2 * m.polish_max, why3, true)) need_roll = false;
-          else {
-            for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
-            __syncthreads();
-            conv = 0;
-          }
-          passes += p2;
-        }
-      }
     }
   }
-  if constexpr (sizeof(TQ) == 4) {
-    // float: an interior point that broke down before its tolerance (a stage Hessian lost definiteness in float -- seen at N = 50 with the
-    // complementarity below 1e-5 --, or the iteration cap) leaves a feasible interior iterate: the active-set method takes over from it
-    if ((st == 4 || st == 2) && need_roll) {
-      int finite = 1;
-      for (int i = tid; i < nv; i += 64) { const TQ v = S[L.z + i]; if (!(tabs(v) < TQ(1e30)) || !(S[L.sl + i] > TQ(0)) || !(S[L.su + i] > TQ(0))) finite = 0; }
-      if (wave_min(finite)) {
-        for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
-        __syncthreads();
-        int p2 = 0, why3 = 0;
-        if (active_set(gm, p2, false, 2 * m.polish_max, why3, true)) { need_roll = false; st = 0; }
-        else {
-          for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
-          __syncthreads();
-        }
-        passes += p2;
-      }
-    }
-  }
-  if (need_roll) {   // state trajectory of the returned z (the interior point's own answer: the active-set method did not settle)
-    PF_START();
-    if constexpr (sizeof(TQ) == 8) rollout<C>(m, S, A, L, L.dx, L.z, true);
-    else {
-      for (int i = tid; i < nv; i += 64) D[L.zd + i] = (double)S[L.z + i];
-      if (tid < VS) D[L.dxd + tid] = tid < NX ? D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)] : 0.0;
-      __syncthreads();
-      rollout64<C>(m, D, S, A, L);
-    }
-    PF_STOP(PF_ROLL);
-  }
-  *status = (st == 0 && !conv) ? 8 : st;
+  if (need_roll) { PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z
+  *status = st;
   // bound states that differ between the previous solution (z = 0: on a bound where lb or ub is 0) and this one
   int chg = 0;
   if (m.flip_max >= 0 && prev_iter > 0) {
@@ -2516,7 +2505,92 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
   {   // factorisations: warm passes + interior-point iterations + passes behind it; sweeps: one per pass, two forward + one backward
       // (+ the adjoint in fp32) per interior-point iteration, rollout + adjoint of the interior start, the final rollout
     const int wp = wpasses % 1000;
-    *work = (it + passes + wp) | ((wp + passes + (sizeof(TQ) == 4 ? 4 : 3) * it + 2 + (need_roll ? 1 : 0)) << 16);
+    *work = (it + passes + wp) | ((wp + passes + 3 * it + 2 + (need_roll ? 1 : 0)) << 16);
+  }
+  return it + passes + wpasses + (m.flip_max >= 0 && chg > m.flip_max ? 10000 : 0) + 100000 * why;
+}
+
+// Box-QP solve of the float instances (mixed precision).  Same three stages as solve_qp -- (0) warm active-set attempt, (1) interior
+// point to the hand-over tolerance + active set from its working set, (2) interior point to its last tolerance + active set without the
+// early exit -- written as ONE loop so that the interior point and the active-set method are each instantiated once in the kernel (as four
+// inlined copies of polish_mixed the float instances were 370 KB of code and lost 8 % to instruction fetch).  What differs from fp64: the
+// answer always comes from the active-set method (its iterate and residuals are double); an interior point that breaks down in float --
+// a stage Hessian losing definiteness, the iteration cap -- leaves a feasible iterate from which stage 2 takes over; only if the
+// active-set method fails behind stage 2 as well is the interior point's own answer taken, and reported (MPCQ_SOLVE_LOW_ACCURACY).
+template <typename C, bool GAB = C::GAB>
+MPCQ_PHASE int solve_qp_mixed(const DevModel<float>& m, P<double> D, P<float> S, P<float> A, P<float> G, const Lds& L, int* status, const int prev_iter, int* work PF_ARG) {
+  using TQ = float;
+  const int N = cN<C>(m), nv = N * NU, tid = lane_id();
+  int it = 0, passes = 0, wpasses = 0, why = 0, conv = 1, st = 0;
+  TQ gm = 1;
+  const P<TQ> Kb = C::GK ? G : S;
+  const bool flipping = m.flip_max >= 0 && (prev_iter / 10000) % 10 != 0;   // (prev_iter, flip mark, budgets: see solve_qp)
+  const int warm_cap = flipping ? 0 : ((prev_iter / 1000) % 10 != 0 ? m.warm_retry : m.warm_max);
+  if (flipping) { wpasses = 1000; why = QPX_SKIPPED; }
+  bool solved = false, ipm_sound = true;
+  for (int stage = (prev_iter > 0 && warm_cap > 0) ? 0 : 1; stage <= 2 && !solved && ipm_sound; ++stage) {
+    int cap = warm_cap;
+    if (stage >= 1) {
+      // D[L.dxd] shares its space with the float vectors dx | Dx: behind an active-set attempt dx_0 = x_meas - X_0 is put back
+      if (tid < VS) S[L.dx + tid] = tid < NX ? (TQ)(D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)]) : TQ(0);
+      if (stage == 1) {   // interior start: the previous solution (z = 0) pushed inside the box
+        for (int i = tid; i < nv; i += 64) {
+          const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
+          const TQ z0 = tmin(tmax(TQ(0), lb + m.ipm_margin * w), ub - m.ipm_margin * w);
+          S[L.z + i] = z0; S[L.sl + i] = z0 - lb; S[L.su + i] = ub - z0;
+        }
+      } else {            // continue from the interior point's last iterate
+        for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
+      }
+      __syncthreads();
+      PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+      PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
+      if (stage == 1) {
+        gm = 1;
+        for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
+        gm = wave_max(gm);
+        for (int i = tid; i < nv; i += 64) { S[L.ll + i] = m.ipm_mu0 * gm / S[L.sl + i]; S[L.lu + i] = m.ipm_mu0 * gm / S[L.su + i]; }
+        __syncthreads();
+      }
+      st = ipm_run<C>(m, S, A, Kb, L, (stage == 1 && m.polish_max > 0) ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+      if (st != 0) {   // broken down before its tolerance: is the iterate it leaves usable?
+        int finite = (st == 4 || st == 2) ? 1 : 0;
+        for (int i = tid; i < nv; i += 64) { const TQ v = S[L.z + i]; if (!(tabs(v) < TQ(1e30)) || !(S[L.sl + i] > TQ(0)) || !(S[L.su + i] > TQ(0))) finite = 0; }
+        ipm_sound = wave_min(finite) != 0;
+        stage = 2;       // whatever follows is the last resort
+      }
+      if (!ipm_sound || m.polish_max <= 0) break;
+      for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
+      __syncthreads();
+      cap = stage == 1 ? m.polish_max : 4 * m.polish_max;
+    }
+    int np = 0, wy = 0;
+    solved = polish_mixed<C>(m, D, S, A, Kb, L, gm, np, stage == 0, cap, wy, conv, stage == 2 PF_PASS);
+    if (stage == 0) { wpasses = np; if (!solved) { why = wy; wpasses += 1000; } }
+    else passes += np;
+  }
+  if (solved) st = 0;
+  else {   // the interior point's own answer (or, behind a breakdown, its last iterate): reported
+    for (int i = tid; i < nv; i += 64) D[L.zd + i] = (double)S[L.z + i];
+    if (tid < VS) D[L.dxd + tid] = tid < NX ? D[L.x0 + i2o(tid)] - D[L.X + i2o(tid)] : 0.0;
+    __syncthreads();
+    PF_START(); rollout64<C>(m, D, S, A, L); PF_STOP(PF_ROLL);
+    conv = 0;
+  }
+  *status = (st == 0 && !conv) ? 8 : st;
+  // bound states that differ between the previous solution (z = 0: on a bound where lb or ub is 0) and this one
+  int chg = 0;
+  if (m.flip_max >= 0 && prev_iter > 0 && wpasses >= 1000) {
+    for (int i = tid; i < nv; i += 64) {
+      const TQ lb = S[L.lb + i], ub = S[L.ub + i], z = S[L.z + i];
+      const int was = lb == TQ(0) ? -1 : (ub == TQ(0) ? 1 : 0), is = z == lb ? -1 : (z == ub ? 1 : 0);
+      chg += was != is ? 1 : 0;
+    }
+    chg = wave_sum(chg);
+  }
+  {   // (counts as in solve_qp; a refinement step is charged as a pass: two sweeps, no factorisation)
+    const int wp = wpasses % 1000;
+    *work = (it + passes + wp) | ((2 * (wp + passes) + 4 * it + 2) << 16);
   }
   return it + passes + wpasses + (m.flip_max >= 0 && chg > m.flip_max ? 10000 : 0) + 100000 * why;
 }
@@ -2772,7 +2846,9 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   int status = 0;
   const int prev_iter = st.qp_iter[b];
   int work = 0;
-  const int iters = solve_qp<C>(m, D, S, A, G, L, &status, prev_iter, &work PF_PASS);
+  int iters;
+  if constexpr (sizeof(TQ) == 4) iters = solve_qp_mixed<C>(m, D, S, A, G, L, &status, prev_iter, &work PF_PASS);
+  else iters = solve_qp<C>(m, D, S, A, G, L, &status, prev_iter, &work PF_PASS);
 #ifdef MPCQ_TRACE_NAN
   trace(2, nonfinite(S, L.z, nv) | nonfinite(S, L.dx, (N + 1) * VS) << 1 | (unsigned long long)(status & 0xff) << 8 | (unsigned long long)(unsigned)iters << 32);
 #endif
