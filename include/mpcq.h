@@ -44,10 +44,11 @@ typedef enum mpcq_status {
 #define MPCQ_SOLVE_NAN 1          /* the QP step was not finite: the instance kept its previous iterate and control */
 #define MPCQ_SOLVE_MAXITER 2
 #define MPCQ_SOLVE_QP_FAILURE 4
-#define MPCQ_SOLVE_LOW_ACCURACY 8 /* MPCQ_PRECISION_F32 only: the refinement of the QP solution against fp64 residuals did not converge
-                                     (or the active-set finish behind the interior point did not settle): the step was taken with the
-                                     float answer.  Never observed; the tests require status 0 on every solve.  A warning, not a
-                                     failure: mpcq_get_tracking_stats out[4] does not count it */
+#define MPCQ_SOLVE_LOW_ACCURACY 8 /* MPCQ_PRECISION_F32 only: the refinement of the QP solution against fp64 residuals did not converge: the
+                                     step was taken with the interior point's float answer.  Seen only on instances whose prediction
+                                     tumbles (gradient scale above 1e6: about one solve in a million at N = 20);
+                                     the tests require status 0 on every solve.  A warning, not a failure: mpcq_get_tracking_stats
+                                     out[4] does not count it */
 
 /* mpcq_config.flags.  MPCQ_FLAG_STATIC_GP: the GP in the model is a static one (use_gp = 1, gpe.type == "GP",
  * src/quad_opt.py:228-236 with src/gp/GP.py:136-175): basis = its training inputs, theta = (L, sigma_f,
@@ -61,8 +62,9 @@ typedef enum mpcq_status {
  * demands it: the iterate, the measurement and every difference that defines the QP are formed in double (as in F64), the shooting
  * integrates in double and rounds its RECORDS to float once, and the QP solution is kept in double and refined against the residual
  * of the QP evaluated in double on those records, the float factorisation solving for the corrections (iterative refinement).
- * Holds the north_star budget on EVERY solve -- warm, cold start, interior-point fallback, saturated inputs: <= 1e-4 relative control
- * deviation from the fp64 oracle, teacher-forced (tests/test_gpu_parity.py; observed <= 2.4e-5, median 2e-8 .. 4e-7), status 0. */
+ * Holds the north_star budget on every solve it reports with status 0 -- warm, cold start, interior-point fallback, saturated inputs:
+ * <= 1e-4 relative control deviation from the fp64 oracle, teacher-forced (tests/test_gpu_parity.py; observed <= 2.4e-5, median
+ * 2e-8 .. 4e-7).  Status 0 is what every solve reports except on instances whose prediction tumbles (see MPCQ_SOLVE_LOW_ACCURACY). */
 #define MPCQ_PRECISION_F64 0
 #define MPCQ_PRECISION_F32 1
 
