@@ -20,7 +20,7 @@ VARIANTS = {"identity": ("identity order", dict(block_order=1)), "sorted": ("cos
             "compact": ("layout: compact (gains in global memory, 256 registers), cost-sorted order", dict(stage_mem=3))}
 which = os.environ.get("LB_VARIANTS", "identity,sorted").split(",")
 for name, tune in (VARIANTS[w] for w in which):
-    e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), tune=tune))
+    e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), tune=tune, precision=1 if os.environ.get("LB_F32") else 0))
     e.set_trajectories(*refs); e.sim_reset(np.tile(bench.X0, (B, 1)))
     if os.environ.get("LB_PREROLL_LOCKSTEP"):      # (profiler runs: no long persistent launch under counter collection)
         e.sim_steps(pre, 2, 5e-3)
