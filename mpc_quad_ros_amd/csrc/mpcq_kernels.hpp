@@ -2412,7 +2412,17 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
     full = nblk == 0;
     // wholesale bounce in a saturated regime: leave it to the interior point (not behind its final iterations: last_resort)
     if (released && nblk >= 8 && 2 * (nact + nblk) >= nv && !last_resort) { why = QPX_BOUNCE; return false; }
-    if (nblk > 0) { refactor = true; need_roll = true; gF_prev = -1; if (released && careful < 3) careful += 1; }   // clipped inputs: the sweep's trajectory is not theirs
+    if (nblk > 0) {   // clipped inputs: the sweep's trajectory is not theirs
+      refactor = true; need_roll = true; gF_prev = -1;
+      if (released) {
+        // a release that bounces straight back raises the level of caution; at the last level -- the single worst multiplier released, and
+        // pinned again by a step that leaves the box by a rounding error -- the input is degenerate (it sits on its bound with a multiplier
+        // of zero to rounding): the sign test is loosened until the pair stops trading places (seen on the bench workload's own seed: one
+        // input released and re-pinned sixty times until the budget was gone)
+        if (careful < 3) careful += 1;
+        else tolm *= 100.0;
+      }
+    }
     released = false;
     if (corrected && full) {
       if (dzm <= tol_c) { settled = true; passes += 1; break; }   // (the forward sweep has taken the trajectory along)

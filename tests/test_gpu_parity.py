@@ -227,6 +227,28 @@ def test_whole_trajectories_full_batch(precision):
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("shape", [(1024, 20, 10, 300), (256, 50, 50, 150)], ids=["B1024-N20nb10", "B256-N50nb50"])
+def test_f32_every_solve_of_the_bench_workload_reports_status_zero(shape):
+    """MPCQ_PRECISION_F32 on the bench workload (continuous operation on min-snap flights at v_max = a_max = 12, where some quadrotors
+    saturate and go through the interior point period after period), lockstep, the status of EVERY solve read back: none fails, none
+    reports MPCQ_SOLVE_LOW_ACCURACY (the refinement against fp64 residuals converges everywhere), the swarm keeps tracking.  (Longer runs
+    of the same check: profiles/r5_soak.txt, profiles/r5_f32_hunts.txt.)"""
+    import bench
+    B, N, nb, K = shape
+    refs = bench.workload(2026, 0, B, K + 10)
+    e, _ = bench.make_engine(B, N, nb, 1, 0, 0, 2026, periods=K + 10, refs=refs)
+    fallbacks = 0
+    for k in range(K):
+        e.sim_steps(1, 2, 5e-3)
+        st = e.get_status()
+        assert (st == 0).all(), (k, np.flatnonzero(st != 0), st[st != 0])
+        fallbacks += int(((e.get_qp_iter() // 1000) % 10 != 0).sum())
+    t = e.get_tracking_stats()
+    assert t[2] == K * B and t[4] == 0 and np.sqrt(t[0] / (3 * t[2])) < 0.1
+    assert fallbacks >= 5            # the interior-point path was exercised (1 024 x 300 at N = 20: hundreds; 256 x 150 at N = 50: about ten)
+    e.close()
+
+
 def test_missions_soak_full_batch():
     """The bench workload (continuous operation on min-snap flights at v_max = a_max = 12: some quadrotors saturate for whole
     stretches and need the interior point period after period) at full size for 1 500 control periods: every solve succeeds,
