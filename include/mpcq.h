@@ -46,7 +46,7 @@ typedef enum mpcq_status {
 #define MPCQ_SOLVE_QP_FAILURE 4
 #define MPCQ_SOLVE_LOW_ACCURACY 8 /* MPCQ_PRECISION_F32 only: the refinement of the QP solution against fp64 residuals did not converge: the
                                      step was taken with the interior point's float answer.  Seen only on instances whose prediction
-                                     tumbles (gradient scale above 1e6; none in the 7.8 M solves of the final soaks);
+                                     tumbles (gradient scale above 1e6; none in the 13.6 M solves of the final soaks);
                                      the tests require status 0 on every solve.  A warning, not a failure: mpcq_get_tracking_stats
                                      out[4] does not count it */
 
