@@ -132,6 +132,8 @@ template <typename T> __device__ inline V4<typename std::remove_const<T>::type> 
 template <typename T> __device__ inline void st4(const P<T>& b, long off, const V4<T>& v) {
   if (b.ok(off, 4)) *reinterpret_cast<V4<T>*>(b.p + off) = v;
 }
+// float view of a double region (the float interior point of the fp64 instances works in the space of the double QP vectors)
+__device__ inline P<float> as_float(const P<double>& d) { return P<float>(reinterpret_cast<float*>(d.p), 2 * d.lo, 2 * d.hi, d.tag); }
 #define CK_EXEC_FULL(site) ck_exec(site)
 #else
 constexpr int CK_HDR = 0;
@@ -164,6 +166,8 @@ template <typename T> __device__ inline V4<typename std::remove_const<T>::type> 
   return *reinterpret_cast<const V4<typename std::remove_const<T>::type>*>(&b[off]);
 }
 template <typename T> __device__ inline void st4(const P<T>& b, long off, const V4<T>& v) { *reinterpret_cast<V4<T>*>(&b[off]) = v; }
+// float view of a double region (the float interior point of the fp64 instances works in the space of the double QP vectors)
+__device__ inline P<float> as_float(const P<double>& d) { return P<float>(reinterpret_cast<float*>(d.b), d.o); }
 #define CK_EXEC_FULL(site)
 #endif
 constexpr int ABW = 16;          // row stride of AB'' = [A[:, q v r] | B]: the columns of [A|B] that are not [0;I] (position)
@@ -219,6 +223,11 @@ __device__ inline void pf_stop(Prof& p, int k) { const unsigned long long n = __
 #define PF_FINE(k) pf_stop(pf, k)
 #else
 #define PF_FINE(k)
+#endif
+#if defined(MPCQ_PROFILE) && defined(MPCQ_PROFILE_SERIAL)   // cycle stamps around the single-lane blocks and the parts of the post phase (slots 11..15)
+#define PF_SER(k) pf_stop(pf, k)
+#else
+#define PF_SER(k)
 #endif
 #if defined(MPCQ_PROFILE) && defined(MPCQ_PROFILE_FAC)   // cycle stamps inside a factorisation stage (slots 11..15)
 #define PF_FAC(k) pf_stop(pf, k)
@@ -553,8 +562,9 @@ template <typename T> __device__ inline void mfma(T (&acc)[4], T a, T b) {
 #endif
 // A state-sized vector rides in column 14 of a tile: lane (h, 14) holds slots RI(s,h), s = 0..3.
 template <typename PT> __device__ inline void vl_load(PT base, int h, float (&v)[4]) {   // slots 4h..4h+3: one 128-bit read
-  const V4<float> t = ld4(base, 4 * h);
-  v[0] = t.a; v[1] = t.b; v[2] = t.c; v[3] = t.d;
+  // (double records read by float arithmetic -- the float interior point of the fp64 instances, solve_qp: two 128-bit reads, rounded once)
+  const auto t = ld4(base, 4 * h);
+  v[0] = (float)t.a; v[1] = (float)t.b; v[2] = (float)t.c; v[3] = (float)t.d;
 }
 template <typename PT> __device__ inline void vl_store(PT base, int h, const float (&v)[4]) {
   V4<float> t; t.a = v[0]; t.b = v[1]; t.c = v[2]; t.d = v[3];
@@ -1077,8 +1087,8 @@ MPCQ_COLD void adjoint(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, const Lds& L) {
 }
 
 // backward vector recursion with stored K, Linv: feed-forward k_i (into S[L.vin] slots 0..3) for linear term rho
-template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, bool polish) {
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB, typename M = DevModel<TQ>, typename PA = P<TQ>>
+MPCQ_COLD void riccati_backward_vec(const M& m, P<TQ> S, PA A, P<TQ> Kb, const Lds& L, bool polish) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15, nv = N * NU;
   for (int i = lane; i < nv; i += 64) S[L.vin + GI(i)] = S[L.rho + i];
   __syncthreads();
@@ -1143,8 +1153,8 @@ MPCQ_COLD void riccati_backward_vec(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<T
 // registers (lane (h,c) holds M[c][RI(s,h)], s = 0..3): four FMAs against the group-uniform vector slots x[RI(s,h)], then
 // the sum over the four lane rows (hsum).  The result arrives lane-indexed (lane (.,c) holds row c); the next product needs
 // it group-uniform again: the inputs go through four v_readlane, the state through the LDS vector that the sweep writes anyway.
-template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE void riccati_forward(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, int dzo PF_ARG) {
+template <typename C, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB, typename M = DevModel<TQ>, typename PA = P<TQ>>
+MPCQ_PHASE void riccati_forward(const M& m, P<TQ> S, PA A, P<TQ> Kb, const Lds& L, int dzo PF_ARG) {
   const int N = cN<C>(m), lane = lane_id(), h = lane >> 4, c = lane & 15;
   constexpr bool F64 = sizeof(TQ) == 8;
   const Sel<TQ> sel(h);
@@ -1228,8 +1238,8 @@ template <typename TQ> __device__ inline TQ pin_diag() { return sizeof(TQ) == 8 
 //   P_i  = Q + G + M^T K           with G = [A|B]^T P [A|B] restricted to states, assembled from F'', T1'', P.
 // The 4x4 stage Hessian Lambda = R~ + F''[10:14,10:14] is factorised in registers (Cholesky) by the lanes
 // that need it.  Returns false if a stage Hessian was not positive definite.
-template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_PHASE bool riccati_factor(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L PF_ARG, TQ* gscale = nullptr, P<TQ> mrows = nullptr,
+template <typename C, bool polish, bool affine = false, typename TQ = typename C::T, bool GAB = C::GAB, typename M = DevModel<TQ>, typename PA = P<TQ>>
+MPCQ_PHASE bool riccati_factor(const M& m, P<TQ> S, PA A, P<TQ> Kb, const Lds& L PF_ARG, TQ* gscale = nullptr, P<TQ> mrows = nullptr,
                                       P<TQ> pstore = nullptr, int start = -1, bool have_rt = false, const int pst_valid = 1 << 30, const int pst_store = 1 << 30) {
   const int N = cN<C>(m), lane = lane_id(), nv = N * NU, h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
@@ -1504,8 +1514,8 @@ template <typename TQ, typename PT> __device__ inline void dbg_dump(const DevMod
 #define MPCQ_F32_IPM_INCR 1
 #endif
 template <typename TQ> __device__ constexpr bool IPM_INCR() { return sizeof(TQ) == 8 || MPCQ_F32_IPM_INCR != 0; }
-template <typename C, typename TQ = typename C::T, bool GAB = C::GAB>
-MPCQ_COLD int ipm_run_regs(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG) {
+template <typename C, typename TQ = typename C::T, bool GAB = C::GAB, typename M = DevModel<TQ>, typename PA = P<TQ>>
+MPCQ_COLD int ipm_run_regs(const M& m, P<TQ> S, PA A, P<TQ> Kb, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG, const TQ rd_floor = TQ(3e-4)) {
   constexpr int N = C::N > 0 ? C::N : 1, nv = N * NU, R = (nv + 63) / 64;
   const int tid = lane_id();
   int status = 2;
@@ -1537,7 +1547,7 @@ MPCQ_COLD int ipm_run_regs(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, co
     // (float: the dual residual comes from a float gradient sweep whose own noise is ~1e-4 of the gradient scale on ill-conditioned
     //  instances -- asked for less, the iteration oscillates around that floor until its cap (1 solve in 3e5 at N = 50); what the
     //  active-set method behind needs from here is the complementarity, the residual it evaluates itself in double)
-    if (rdm <= (sizeof(TQ) == 4 ? tmax(tol, TQ(3e-4)) : tol) * gm && mu <= tol) { status = 0; break; }
+    if (rdm <= (sizeof(TQ) == 4 ? tmax(tol, rd_floor) : tol) * gm && mu <= tol) { status = 0; break; }
     // predictor: (H + Sigma) dza = -grad
     TQ rsl[R], rsu[R];
 #pragma unroll
@@ -1547,11 +1557,11 @@ MPCQ_COLD int ipm_run_regs(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, co
     }
     __syncthreads();
     PF_START();
-    const bool fok = riccati_factor<C, false>(m, S, A, Kb, L PF_PASS, (TQ*)nullptr, P<TQ>(nullptr), P<TQ>(nullptr), -1, true);
+    const bool fok = riccati_factor<C, false, false, TQ, GAB>(m, S, A, Kb, L PF_PASS, (TQ*)nullptr, P<TQ>(nullptr), P<TQ>(nullptr), -1, true);
     PF_STOP(PF_FACTOR);
     if (it == 0) { DBG_DUMP(2, 0, S, L.rt, nv); DBG_DUMP(2, 128, Kb, L.K, N * KS); DBG_DUMP(2, 2048, Kb, L.Linv, N * 16); DBG_DUMP(2, 3000, S, L.vin, N * VS); }
     if (!fok) { status = 4; break; }
-    PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dza PF_PASS); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C, false, TQ, GAB>(m, S, A, Kb, L, L.dza PF_PASS); PF_STOP(PF_FWD);
     if (it == 0) { DBG_DUMP(3, 0, S, L.dza, nv); DBG_DUMP(3, 128, S, L.Dx, (N + 1) * VS); }
     // step lengths without divisions: alpha = 1 / max_i(-ds_i / s_i); every quotient is a product with a reciprocal
     TQ da[R], dla[R], dua[R], rll[R], rlu[R], ainv = 1;
@@ -1584,9 +1594,9 @@ MPCQ_COLD int ipm_run_regs(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, co
       if (on[r]) S[L.rho + ix[r]] = rho[r];
     }
     __syncthreads();
-    PF_START(); riccati_backward_vec<C>(m, S, A, Kb, L, false); PF_STOP(PF_BWD);
+    PF_START(); riccati_backward_vec<C, TQ, GAB>(m, S, A, Kb, L, false); PF_STOP(PF_BWD);
     if (it == 0) { DBG_DUMP(4, 0, S, L.rho, nv); DBG_DUMP(4, 128, S, L.vin, N * VS); }
-    PF_START(); riccati_forward<C>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
+    PF_START(); riccati_forward<C, false, TQ, GAB>(m, S, A, Kb, L, L.dz PF_PASS); PF_STOP(PF_FWD);
     if (it == 0) { DBG_DUMP(5, 0, S, L.dz, nv); DBG_DUMP(5, 128, S, L.Dx, (N + 1) * VS); }
     TQ d[R], dl[R], du[R], apinv = 1, adinv = 1;
 #pragma unroll
@@ -1618,8 +1628,8 @@ MPCQ_COLD int ipm_run_regs(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> Kb, co
     }
     for (int i = tid; i < (N + 1) * VS; i += 64) S[L.dx + i] += ap * S[L.Dx + i];
     __syncthreads();
-    if (!IPM_INCR<TQ>()) {
-      PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
+    if constexpr (!IPM_INCR<TQ>()) {
+      PF_START(); adjoint<C, TQ, GAB>(m, S, A, L); PF_STOP(PF_ADJ);
 #pragma unroll
       for (int r = 0; r < R; ++r) g[r] = S[L.grad + gi[r]];
     }
@@ -1817,7 +1827,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
       __syncthreads();
       PF_START();
       TQ gfac = 0;
-#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD) && !defined(MPCQ_PROFILE_FAC)
+#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD) && !defined(MPCQ_PROFILE_FAC) && !defined(MPCQ_PROFILE_SERIAL)
       pf.acc[13] += (keep_p ? pst_first(N, top, pst_hi) : N - 1) + 1;   // stages this factorisation visits
       pf.acc[14] += 1;                                                    // factorisations
 #endif
@@ -1943,7 +1953,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) printf("     pass %d feasible %d nblk %d release %d\n", passes, (int)feasible, nblk, (int)any_release);
 #endif
-#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD) && !defined(MPCQ_PROFILE_FAC)
+#if defined(MPCQ_PROFILE) && !defined(MPCQ_PROFILE_FWD) && !defined(MPCQ_PROFILE_FAC) && !defined(MPCQ_PROFILE_SERIAL)
     pf.acc[11] += nblk;                        // inputs pinned
     pf.acc[12] += any_release ? 1 : 0;         // passes with a release
     pf.acc[15] += (any_release && nblk > 0) ? 1 : 0;   // passes with both
@@ -2440,6 +2450,84 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
   return settled;
 }
 
+// ------------------------------------------------------------------ fp64 instances: the interior point of the fallback in float
+// What the active-set method behind the interior point takes over is a WORKING SET (which inputs sit on which bound), checked and
+// corrected by its own double factorisations -- the answer of a fallback solve never comes from the interior point.  Its iterations
+// therefore run in float on the matrix cores' float tiles (v_mfma_f32_16x16x4_f32: half the passes of the f64 tile, 32-bit DPP and
+// LDS traffic), with the operands read from the double stage records and rounded in registers.  The float vectors live in the space of
+// the double ones (float array X = the first half of the bytes of double array X: offsets x 2 in a float view of the same LDS), so the
+// layout and the LDS budget of the instance do not change.  The interior point is the one the float instances run (ipm_run_regs<float>:
+// centring floor, float residual test).  Returns false when it broke down (the caller then runs the double interior point from its
+// start): the double start vectors are overwritten either way.  -DMPCQ_HYBRID_IPM=0: the double interior point (rounds 1-4).
+#ifndef MPCQ_HYBRID_IPM
+#define MPCQ_HYBRID_IPM 1
+#endif
+#ifndef MPCQ_HYBRID_TOL   // hand-over tolerance of the float interior point (the float instances: 1e-5)
+#define MPCQ_HYBRID_TOL 3e-7f
+#endif
+#ifndef MPCQ_HYBRID_RD    // what it asks of its float dual residual, in units of the gradient scale (the float instances: 3e-4)
+#define MPCQ_HYBRID_RD 3e-4f
+#endif
+template <typename C, bool GAB = C::GAB>
+MPCQ_COLD bool ipm_float_stage(const DevModel<double>& m, P<double> S, P<double> A, P<double> Kb, const Lds& L, const double gm, int& it PF_ARG) {
+  constexpr int N = C::N, nv = N * NU, R = (nv + 63) / 64, RG = (N * VS + 63) / 64;
+  const int tid = lane_id();
+  Lds Lf = L;   // stage records: the double ones (offsets into A unchanged); QP workspace and gains: the float view
+  Lf.z = 2 * L.z; Lf.sl = 2 * L.sl; Lf.su = 2 * L.su; Lf.ll = 2 * L.ll; Lf.lu = 2 * L.lu; Lf.dza = 2 * L.dza; Lf.dz = 2 * L.dz;
+  Lf.rho = 2 * L.rho; Lf.act = 2 * L.act; Lf.rt = 2 * L.rt; Lf.grad = 2 * L.grad; Lf.vin = 2 * L.vin; Lf.dx = 2 * L.dx; Lf.Dx = 2 * L.Dx;
+  Lf.K = 2 * L.K; Lf.Linv = 2 * L.Linv; Lf.sF = 2 * L.sF; Lf.sT = 2 * L.sT; Lf.stv = 2 * L.stv; Lf.wq = 2 * L.wq;
+  const P<float> Sf = as_float(S), Kf = as_float(Kb);
+  // the start, read in double and rounded behind a barrier (a float array overlaps the double elements of other lanes)
+  double zr[R], slr[R], sur[R], llr[R], lur[R], gr[RG];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + 64 * r, ii = i < nv ? i : 0;
+    zr[r] = S[L.z + ii]; slr[r] = S[L.sl + ii]; sur[r] = S[L.su + ii]; llr[r] = S[L.ll + ii]; lur[r] = S[L.lu + ii];
+  }
+#pragma unroll
+  for (int r = 0; r < RG; ++r) { const int k = tid + 64 * r; gr[r] = S[L.grad + (k < N * VS ? k : 0)]; }
+  const double wqr = S[L.wq + (tid < 3 * VS ? tid : 0)];   // live in double behind the interior point: kept here, put back below
+  const double dx0r = S[L.dx + (tid < VS ? tid : 0)];       // dx_0 likewise
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + 64 * r;
+    if (i < nv) { Sf[Lf.z + i] = (float)zr[r]; Sf[Lf.sl + i] = (float)slr[r]; Sf[Lf.su + i] = (float)sur[r]; Sf[Lf.ll + i] = (float)llr[r]; Sf[Lf.lu + i] = (float)lur[r]; }
+  }
+#pragma unroll
+  for (int r = 0; r < RG; ++r) { const int k = tid + 64 * r; if (k < N * VS) Sf[Lf.grad + k] = (float)gr[r]; }
+  if (tid < 3 * VS) Sf[Lf.wq + tid] = (float)wqr;
+  for (int i = tid; i < (N + 1) * VS; i += 64) Sf[Lf.dx + i] = 0;   // (the float state trajectory is bookkeeping nobody reads)
+  __syncthreads();
+  int itf = 0;
+  const int stf = ipm_run_regs<C, float, GAB>(m, Sf, A, Kf, Lf, MPCQ_HYBRID_TOL, (float)gm, itf PF_PASS, MPCQ_HYBRID_RD);
+  it += itf;
+  // back to double: the smaller slack of an input is taken as it is, the point and the other slack follow from it (both positive, and
+  // consistent with the bounds to double rounding -- what a continuation in double needs)
+  float zf[R], slf[R], suf[R], llf[R], luf[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + 64 * r, ii = i < nv ? i : 0;
+    zf[r] = Sf[Lf.z + ii]; slf[r] = Sf[Lf.sl + ii]; suf[r] = Sf[Lf.su + ii]; llf[r] = Sf[Lf.ll + ii]; luf[r] = Sf[Lf.lu + ii];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = tid + 64 * r;
+    if (i < nv) {
+      const double lb = S[L.lb + i], ub = S[L.ub + i];
+      double z, sl, su;
+      if (slf[r] <= suf[r]) { sl = (double)slf[r]; z = lb + sl; su = ub - z; }
+      else { su = (double)suf[r]; z = ub - su; sl = z - lb; }
+      S[L.z + i] = z; S[L.sl + i] = sl; S[L.su + i] = su; S[L.ll + i] = (double)llf[r]; S[L.lu + i] = (double)luf[r];
+    }
+  }
+  if (tid < 3 * VS) S[L.wq + tid] = wqr;
+  if (tid < VS) S[L.dx + tid] = dx0r;
+  __syncthreads();
+  return stf == 0;
+}
+
 // Box-QP solve.  (1) Warm active-set attempt: the RTI iterate is persisted, so the working set of the
 // previous control step (inputs sitting exactly on a bound) is usually still optimal or off by one or two
 // inputs; a few passes of the active-set method from z = 0 then end on the exact KKT point at the cost of
@@ -2478,22 +2566,33 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
   }
   int st = 0;
   // interior start
-  for (int i = tid; i < nv; i += 64) {
-    const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
-    const TQ z0 = tmin(tmax(TQ(0), lb + m.ipm_margin * w), ub - m.ipm_margin * w);
-    S[L.z + i] = z0; S[L.sl + i] = z0 - lb; S[L.su + i] = ub - z0;
-  }
-  __syncthreads();
-  PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
-  PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
-  gm = 1;
-  for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
-  gm = wave_max(gm);
-  for (int i = tid; i < nv; i += 64) { S[L.ll + i] = m.ipm_mu0 * gm / S[L.sl + i]; S[L.lu + i] = m.ipm_mu0 * gm / S[L.su + i]; }
-  __syncthreads();
+  auto interior_start = [&]() {
+    for (int i = tid; i < nv; i += 64) {
+      const TQ lb = S[L.lb + i], ub = S[L.ub + i], w = ub - lb;
+      const TQ z0 = tmin(tmax(TQ(0), lb + m.ipm_margin * w), ub - m.ipm_margin * w);
+      S[L.z + i] = z0; S[L.sl + i] = z0 - lb; S[L.su + i] = ub - z0;
+    }
+    __syncthreads();
+    PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
+    PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
+    gm = 1;
+    for (int i = tid; i < nv; i += 64) gm = tmax(gm, tabs(S[L.grad + GI(i)]));
+    gm = wave_max(gm);
+    for (int i = tid; i < nv; i += 64) { S[L.ll + i] = m.ipm_mu0 * gm / S[L.sl + i]; S[L.lu + i] = m.ipm_mu0 * gm / S[L.su + i]; }
+    __syncthreads();
+  };
+  interior_start();
   DBG_DUMP(1, 0, S, L.z, nv); DBG_DUMP(1, 128, S, L.sl, nv); DBG_DUMP(1, 256, S, L.su, nv); DBG_DUMP(1, 384, S, L.ll, nv); DBG_DUMP(1, 512, S, L.lu, nv);
   DBG_DUMP(1, 640, S, L.grad, N * VS); DBG_DUMP(1, 1024, S, L.dx, (N + 1) * VS); DBG_DUMP(1, 1536, A, L.AB, N * ABS > 2500 ? 2500 : N * ABS);
-  st = ipm_run<C>(m, S, A, Kb, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+  // shapes whose interior point runs in registers: its iterations to the hand-over in float (ipm_float_stage); broken down -> in double from the start
+  bool handed = false;
+  if constexpr (MPCQ_HYBRID_IPM != 0 && C::N > 0 && C::N * NU <= 128) {
+    if (m.polish_max > 0) {
+      handed = ipm_float_stage<C>(m, S, A, Kb, L, gm, it PF_PASS);
+      if (!handed) interior_start();
+    }
+  }
+  if (!handed) st = ipm_run<C>(m, S, A, Kb, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
   bool need_roll = true;
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
@@ -2761,6 +2860,7 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   };
   load_block(0);
   if (mode & MODE_PLANT_FIRST) {
+    PF_SER(PF_LOAD);
     if (tid == 0) {
       double x[NX], u[NU];
 #pragma unroll
@@ -2771,6 +2871,7 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
 #pragma unroll
       for (int k = 0; k < NX; ++k) { gRunX[k] = x[k]; D[L.x0 + k] = x[k]; }   // the new plant state IS this period's measurement
     }
+    PF_SER(11);
   }
   const bool meas_from_plant = (mode & MODE_PLANT_FIRST) != 0;   // then lane 0 has already put it into LDS (no store -> load hand-over through memory)
   const double xm = (tid < NX && !meas_from_plant) ? mk(st.x_meas + (size_t)b * NX, NX, CK_XMEAS)[tid] : 0.0;
@@ -2944,6 +3045,7 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
   if (regress) {   // stage the covariance while lane 0 integrates the nominal model (QP workspace is dead)
     for (int i = tid; i < 3 * nb * nb; i += 64) S[L.rgp + i] = gCov[i];
   }
+  PF_SER(PF_POST);
   if (tid == 0) {
     double x[NX], u[NU], xp[NX];
 #pragma unroll
@@ -2951,6 +3053,7 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
 #pragma unroll
     for (int k = 0; k < NU; ++k) u[k] = D[L.U + k];
     rk4_nominal(m, x, u, m.dt_pred, xp);
+    PF_SER(12);
     // compute_a_drag (src/utils/utils.py:934-950) against the previous step's prediction
     double xq[NX];
     const bool hp = pre[NX + 4] != 0.0;
@@ -2988,7 +3091,9 @@ __global__ void __launch_bounds__(64, C::GK ? 2 : MPCQ_MIN_WAVES_PER_EU) step_ke
     if ((mode & MODE_TRAJ) && idx + 2 == len && sqrt(ep) < m.finish_r) st.finished[b] = 1;
   }
   __syncthreads();
+  PF_SER(13);
   if (regress) rgp_regress<C>(m, S, L, gmu, gCov, vbad, vbad + 3, true);
+  PF_SER(14);
   }
   if (C::RUN) {   // the plant produces the next measurement (plant_kernel of the lockstep path)
     if (tid == 0) {

@@ -11,12 +11,11 @@
 #include <cstdio>
 using namespace mpcq;
 
-__global__ __launch_bounds__(64) void factor_chain(double* out, int stages) {
-  typedef double TQ;
+template <typename TQ> __global__ __launch_bounds__(64) void factor_chain(double* out, int stages) {
   const int lane = lane_id(), h = lane >> 4, c = lane & 15;
   const bool vl = c == 14;
   TQ Pop[4], cur[4], pv[4], qdg[4];
-  for (int s = 0; s < 4; ++s) { Pop[s] = 1e-3 * (lane + s); cur[s] = 1e-2 * (c - h + s); pv[s] = 1e-3 * s; qdg[s] = (RI<TQ>(s, h) == c) ? 1.0 : 0.0; }
+  for (int s = 0; s < 4; ++s) { Pop[s] = TQ(1e-3) * (lane + s); cur[s] = TQ(1e-2) * (c - h + s); pv[s] = TQ(1e-3) * s; qdg[s] = (RI<TQ>(s, h) == c) ? TQ(1) : TQ(0); }
   for (int i = 0; i < stages; ++i) {
     TQ acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
     for (int s = 0; s < 4; ++s) mfma(acc1, Pop[s], cur[s]);
@@ -26,7 +25,7 @@ __global__ __launch_bounds__(64) void factor_chain(double* out, int stages) {
     TQ Lm[4][4];
     for (int a = 0; a < 4; ++a)
       for (int q = 0; q <= a; ++q) Lm[a][q] = bc(acc2[in_s<TQ>(a)], 16 * in_h<TQ>(a) + 10 + q);
-    for (int a = 0; a < 4; ++a) Lm[a][a] += 1.0;
+    for (int a = 0; a < 4; ++a) Lm[a][a] += TQ(1);
     TQ id[4], cm[4][4];
     for (int cc = 0; cc < 4; ++cc) {
       TQ d = Lm[cc][cc];
@@ -54,24 +53,23 @@ __global__ __launch_bounds__(64) void factor_chain(double* out, int stages) {
     for (int j = 0; j < 4; ++j) dot += y[j] * acc1[j];
     const TQ pcol = c < NX ? acc1[0] - dot : TQ(0);
     TQ C4[4];
-    for (int s = 0; s < 4; ++s) C4[s] = 0.5 * acc2[s] + 0.25 * acc1[s] + 0.125 * Pop[s] + qdg[s];
+    for (int s = 0; s < 4; ++s) C4[s] = TQ(0.5) * acc2[s] + TQ(0.25) * acc1[s] + TQ(0.125) * Pop[s] + qdg[s];
     mfma(C4, mop, kk);
-    for (int s = 0; s < 4; ++s) Pop[s] = 1e-3 * C4[s];      // (scaled: keeps the mock values bounded over many stages)
-    l2g<TQ>(1e-3 * pcol, h, pv);
+    for (int s = 0; s < 4; ++s) Pop[s] = TQ(1e-3) * C4[s];      // (scaled: keeps the mock values bounded over many stages)
+    l2g<TQ>(TQ(1e-3) * pcol, h, pv);
   }
   out[blockIdx.x * 64 + lane] = Pop[0] + pv[1];
 }
 
-__global__ __launch_bounds__(64) void sweep_chain(double* out, int stages) {
-  typedef double TQ;
+template <typename TQ> __global__ __launch_bounds__(64) void sweep_chain(double* out, int stages) {
   const int lane = lane_id(), h = lane >> 4, c = lane & 15;
-  TQ qa[4], xc = 1e-3 * c;
-  for (int s = 0; s < 4; ++s) qa[s] = 1e-2 * (c - h + s);
+  TQ qa[4], xc = TQ(1e-3) * c;
+  for (int s = 0; s < 4; ++s) qa[s] = TQ(1e-2) * (c - h + s);
   for (int i = 0; i < stages; ++i) {
     TQ xv[4];
     l2g<TQ>(xc, h, xv);
     const TQ ta = (qa[0] * xv[0] + qa[1] * xv[1]) + (qa[2] * xv[2] + qa[3] * xv[3]);
-    xc = hsum(ta) + 1e-3;
+    xc = hsum(ta) + TQ(1e-3);
   }
   out[blockIdx.x * 64 + lane] = xc;
 }
@@ -90,8 +88,11 @@ template <typename K> static double run(K k, double* out, int B, int stages) {
 int main() {
   const int B = 1024, stages = 20000;   // one wavefront per SIMD, as a lockstep launch at B = 1024
   double* out; (void)hipMalloc(&out, (size_t)B * 64 * sizeof(double));
-  const double f = run(factor_chain, out, B, stages), s = run(sweep_chain, out, B, stages);
-  printf("{\"factor_stage_chain_ns\": %.1f, \"sweep_stage_chain_ns\": %.1f, \"workgroups\": %d, \"stages\": %d, "
-         "\"note\": \"dependent chain only, registers only, one wavefront per SIMD (tools/microbench/chain_floor.hip)\"}\n", f, s, B, stages);
+  const double f = run(factor_chain<double>, out, B, stages), s = run(sweep_chain<double>, out, B, stages);
+  // float: the interior point of the fp64 instances' fallback runs in float (ipm_float_stage): v_mfma_f32_16x16x4_f32, v_rcp_f32, 32-bit DPP
+  const double ff = run(factor_chain<float>, out, B, stages), sf = run(sweep_chain<float>, out, B, stages);
+  printf("{\"factor_stage_chain_ns\": %.1f, \"sweep_stage_chain_ns\": %.1f, \"factor_stage_chain_f32_ns\": %.1f, \"sweep_stage_chain_f32_ns\": %.1f, "
+         "\"workgroups\": %d, \"stages\": %d, "
+         "\"note\": \"dependent chain only, registers only, one wavefront per SIMD (tools/microbench/chain_floor.hip)\"}\n", f, s, ff, sf, B, stages);
   return 0;
 }
