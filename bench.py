@@ -59,29 +59,37 @@ def latency_roofline(e, n_sub, N, launches=20):
     """What bounds a lockstep launch is not bytes but the dependent instruction chain of its slowest quadrotor.  Floor of that
     chain: (factorisations x N stages x the measured latency of one factorisation stage's dependent chain) + (sweeps x N x the
     measured chain of one sweep stage) -- both from tools/microbench/chain_floor.hip (registers only, nothing but the chain;
-    profiles/r4_chain_floor.json) -- + the non-QP phases at their measured cost.  `launches` further lockstep periods, one call
-    each, with the work counters (mpcq_get_qp_work) and the launch time read back after every one."""
+    profiles/r5_chain_floor.json) -- + the non-QP phases at their measured cost.  The interior-point iterations of a fallback solve
+    of the fp64 instances run in float (csrc/mpcq_kernels.hpp ipm_float_stage): their factorisation and their three sweeps are priced
+    with the float chains, unless the work word says the float interior point broke down (then everything is double).  `launches`
+    further lockstep periods, one call each, with the work counters (mpcq_get_qp_work) and the launch time read back after every one."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r4_chain_floor.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r5_chain_floor.json")) as fh:
             fl = json.load(fh)
     except (OSError, ValueError):
         return None
+    float_ipm = e.cfg.precision == 0 and 4 * N <= 128      # the shapes whose interior point runs in registers (ipm_run_regs)
     floor, got, slow_fac, slow_ipm = [], [], [], []
     for _ in range(launches):
         e.sim_steps(1, n_sub, 5e-3)
         kt, _kl = e.get_kernel_time()
         fac, swp = e.get_qp_work()
-        chain_ns = (fac * fl["factor_stage_chain_ns"] + swp * fl["sweep_stage_chain_ns"]) * N
+        # interior-point iterations of a solve: a fallback solve executes 2 it + 2 (+1) more sweeps than factorisations (solve_qp's work count)
+        ipm = np.where(qp_fallback(e.get_qp_iter()), np.maximum(0, (swp - fac - 2) // 2), 0)
+        ipm_f = np.where(e.get_qp_float_breakdown(), 0, ipm) if float_ipm else np.zeros_like(ipm)
+        chain_ns = ((fac - ipm_f) * fl["factor_stage_chain_ns"] + ipm_f * fl["factor_stage_chain_f32_ns"]
+                    + (swp - 3 * ipm_f) * fl["sweep_stage_chain_ns"] + 3 * ipm_f * fl["sweep_stage_chain_f32_ns"]) * N
         floor.append(float(chain_ns.max()) * 1e-6 + NONQP_CHAIN_US * 1e-3)
         got.append(1e3 * kt)
         b = int(np.argmax(chain_ns))
         slow_fac.append(int(fac[b]))
-        # interior-point iterations of that solve: a fallback solve executes 2 it + 2 (+1) more sweeps than factorisations (solve_qp's work count)
-        slow_ipm.append(max(0, (int(swp[b]) - int(fac[b]) - 2) // 2) if qp_fallback(e.get_qp_iter()[b]) else 0)
+        slow_ipm.append(int(ipm[b]))
     return {"bound": "dependent-chain latency of the slowest quadrotor of a launch", "floor_ms": float(np.mean(floor)), "achieved_ms": float(np.mean(got)),
             "frac": float(np.mean(floor) / np.mean(got)), "launches": launches, "slowest_quad_factorisations_mean": float(np.mean(slow_fac)),
-            "slowest_quad_interior_point_iterations_mean": float(np.mean(slow_ipm)),
-            "factor_stage_chain_ns": fl["factor_stage_chain_ns"], "sweep_stage_chain_ns": fl["sweep_stage_chain_ns"], "non_qp_phases_us_measured": NONQP_CHAIN_US,
+            "slowest_quad_interior_point_iterations_mean": float(np.mean(slow_ipm)), "interior_point_iterations_in_float": bool(float_ipm),
+            "factor_stage_chain_ns": fl["factor_stage_chain_ns"], "sweep_stage_chain_ns": fl["sweep_stage_chain_ns"],
+            "factor_stage_chain_f32_ns": fl["factor_stage_chain_f32_ns"], "sweep_stage_chain_f32_ns": fl["sweep_stage_chain_f32_ns"],
+            "non_qp_phases_us_measured": NONQP_CHAIN_US,
             "note": "floor = chain latencies measured in isolation (registers only, one wavefront per SIMD); the product's stage additionally loads its "
                     "operands, hands rows over through LDS, stores gains / cost-to-go and carries ~4x the instructions of the bare chain"}
 

@@ -284,7 +284,7 @@ struct DevState {
   const int* tlen;
   int* status;
   int* qp_iter;
-  int* qp_work;     // [B] what the last solve executed: factorisations | vector sweeps << 16 (mpcq_get_qp_work)
+  int* qp_work;     // [B] what the last solve executed: factorisations (bits 0..14) | float interior point broke down (bit 15) | vector sweeps << 16 (mpcq_get_qp_work)
   int* finished;    // [B] trajectory finished (src/mpc_controller_node.py:374), sticky until new trajectories / reset
   TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
   double* run_x;    // [B][13] plant states of the free-running closed loop (MODE_RUN; aliases x_meas)
@@ -2585,11 +2585,11 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
   DBG_DUMP(1, 0, S, L.z, nv); DBG_DUMP(1, 128, S, L.sl, nv); DBG_DUMP(1, 256, S, L.su, nv); DBG_DUMP(1, 384, S, L.ll, nv); DBG_DUMP(1, 512, S, L.lu, nv);
   DBG_DUMP(1, 640, S, L.grad, N * VS); DBG_DUMP(1, 1024, S, L.dx, (N + 1) * VS); DBG_DUMP(1, 1536, A, L.AB, N * ABS > 2500 ? 2500 : N * ABS);
   // shapes whose interior point runs in registers: its iterations to the hand-over in float (ipm_float_stage); broken down -> in double from the start
-  bool handed = false;
+  bool handed = false, broke = false;
   if constexpr (MPCQ_HYBRID_IPM != 0 && C::N > 0 && C::N * NU <= 128) {
     if (m.polish_max > 0) {
       handed = ipm_float_stage<C>(m, S, A, Kb, L, gm, it PF_PASS);
-      if (!handed) interior_start();
+      if (!handed) { broke = true; interior_start(); }
     }
   }
   if (!handed) st = ipm_run<C>(m, S, A, Kb, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
@@ -2622,7 +2622,8 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
   {   // factorisations: warm passes + interior-point iterations + passes behind it; sweeps: one per pass, two forward + one backward
       // (+ the adjoint in fp32) per interior-point iteration, rollout + adjoint of the interior start, the final rollout
     const int wp = wpasses % 1000;
-    *work = (it + passes + wp) | ((wp + passes + 3 * it + 2 + (need_roll ? 1 : 0)) << 16);
+    // (bit 15: the float interior point broke down and the double one ran from the start -- its iterations are counted too)
+    *work = (it + passes + wp) | (broke ? 0x8000 : 0) | ((wp + passes + 3 * it + 2 + (need_roll ? 1 : 0) + (broke ? 2 : 0)) << 16);
   }
   return it + passes + wpasses + (m.flip_max >= 0 && chg > m.flip_max ? 10000 : 0) + 100000 * why;
 }

@@ -148,7 +148,13 @@ class Engine:
         """(factorisations, vector sweeps) the last solve of every quadrotor executed."""
         out = np.zeros(self.B, np.int32)
         self._check(self.lib.mpcq_get_qp_work(self.h, _lib.i(out)))
-        return out & 0xFFFF, out >> 16
+        return out & 0x7FFF, out >> 16
+
+    def get_qp_float_breakdown(self):
+        """fp64 instances: True where the float interior point of the last (fallback) solve broke down and the double one ran instead."""
+        out = np.zeros(self.B, np.int32)
+        self._check(self.lib.mpcq_get_qp_work(self.h, _lib.i(out)))
+        return (out & 0x8000) != 0
 
     def get_block_order(self):
         """Launch order of the last lockstep period: workgroup p ran quadrotor out[p] (identity when unused)."""

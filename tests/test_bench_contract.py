@@ -47,7 +47,7 @@ def test_single_rank_line():
     assert d["steady_state"]["steps"] == 3 and d["steady_state"]["value"] > 0
     pr = d["per_rank"]
     assert pr["steps_per_s"]["min"] == pr["steps_per_s"]["max"] and len(pr["ranks"]) == 1 and 0.5 < d["efficiency_vs_best_rank"] <= 1.0 + 1e-9
-    # the latency floor of a launch: chain latencies from profiles/r4_chain_floor.json x the work counters read back after every launch
+    # the latency floor of a launch: chain latencies from profiles/r5_chain_floor.json x the work counters read back after every launch
     lr = d["latency_roofline"]
     assert lr["launches"] == 20 and lr["floor_ms"] > 0 and abs(lr["frac"] - lr["floor_ms"] / lr["achieved_ms"]) < 1e-9 and lr["slowest_quad_factorisations_mean"] >= 1
 

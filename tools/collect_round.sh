@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_round.sh r5'): everything profiles/README.md lists for the final build of a round, in one call.
+R=${1:-r5}
+O=gpurun_out; mkdir -p $O
+python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > $O/${R}_gpu_tests.log
+bash tools/collect_profiles.sh ${R}_k20 --gpus 1 --steps 20 --warmup 5 > $O/collect_${R}_k20.log 2>&1
+python3 bench.py > $O/bench_${R}_default.json 2> $O/bench_${R}_default.err
+bash tools/collect_swarm_traffic.sh $R > $O/collect_${R}_swarm.log 2>&1
+LB_F32=1 bash tools/collect_swarm_traffic.sh $R > $O/collect_${R}_swarm_f32.log 2>&1
+{ python tools/profile_phases.py f64 40; python tools/profile_phases.py f32 40; } > $O/${R}_phase_cycles.txt 2>&1
+python tools/straggler_anatomy.py 200 > $O/${R}_straggler_anatomy.txt 2>&1
+{ SOAK_EVERY=1 python tools/soak.py 1500 7; SOAK_EVERY=1 SOAK_NB=20 python tools/soak.py 600 7; SOAK_EVERY=1 SOAK_B=256 SOAK_N=50 SOAK_NB=50 python tools/soak.py 400 7; SOAK_B=8192 python tools/soak.py 600 7;
+  SOAK_EVERY=1 python tools/soak.py 1000 2026; SOAK_EVERY=1 python tools/soak.py 1000 3; } > $O/${R}_soak.txt 2>&1
+tools/microbench/chain_floor > $O/${R}_chain_floor.json 2>&1
+cat $O/${R}_gpu_tests.log; tail -3 $O/${R}_soak.txt

@@ -15,16 +15,16 @@ refs = bench.workload(seed, 0, B, K + 10)
 for prec, name in ((0, "f64"), (1, "f32")):
     e1, _ = bench.make_engine(B, N, nb, prec, 0, 0, seed, periods=K + 10, refs=refs)
     e2, _ = bench.make_engine(B, N, nb, prec, 0, 0, seed, periods=K + 10, refs=refs)
-    bad = 0; fb = 0; low = 0
+    bad = 0; fb = 0; low = 0; brk = 0
     EV = int(os.environ.get("SOAK_EVERY", 100))
     for k0 in range(0, K, EV):
         e1.sim_steps(EV, 2, 5e-3)
-        st = e1.get_status(); bad += int(((st & 7) != 0).sum()); low += int((st == 8).sum()); fb += int((e1.get_qp_iter() >= 1000).sum())
+        st = e1.get_status(); bad += int(((st & 7) != 0).sum()); low += int((st == 8).sum()); fb += int((e1.get_qp_iter() >= 1000).sum()); brk += int(e1.get_qp_float_breakdown().sum())
     e2.sim_run(K, 2, 5e-3)
     s1, s2 = e1.get_state(), e2.get_state()
     same = all(np.array_equal(s1[k], s2[k]) for k in ("X", "U", "mu", "C", "idx"))
     t = e1.get_tracking_stats()
-    print(f"{name}: {K} periods x {B} quadrotors (N = {N}, nb = {nb}); at the {K // EV} sampled periods: failed solves {bad}, MPCQ_SOLVE_LOW_ACCURACY {low}, fallbacks {fb}; "
+    print(f"{name}: {K} periods x {B} quadrotors (N = {N}, nb = {nb}); at the {K // EV} sampled periods: failed solves {bad}, MPCQ_SOLVE_LOW_ACCURACY {low}, fallbacks {fb} (float interior point broken down in {brk}); "
           f"rms pos {np.sqrt(t[0] / (3 * max(t[2], 1))):.4f} m, max {np.sqrt(t[3]):.3f} m, failed instances {t[4]:.0f}; "
           f"lockstep == free-running bitwise: {same}", flush=True)
     e1.close(); e2.close()

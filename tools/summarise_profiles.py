@@ -86,6 +86,7 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     # the bench line of this collection was printed before these counters existed: record them in the tracked copy
     bench["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
     bench["roofline"]["traffic_source"] = t["source"]
+    bench["roofline"]["traffic_note"] = t["note"]
     with open(os.path.join(P, f"{TAG}_bench.json"), "w") as f:
         json.dump(bench, f, indent=1)
 print(json.dumps({k: v for k, v in pmc.items() if not k.startswith("launches") and k != "note"}, indent=1))
