@@ -56,7 +56,9 @@ typedef enum mpcq_status {
  * run the recursive update (mean and covariance stay as they are). */
 #define MPCQ_FLAG_STATIC_GP 1
 
-/* MPCQ_PRECISION_F64 (default): the reference's own arithmetic; <= 1e-7 relative control deviation from the fp64 oracle.
+/* MPCQ_PRECISION_F64 (default): the reference's own arithmetic; <= 1e-7 relative control deviation from the fp64 oracle.  (The interior
+ * point of a fallback solve iterates in float where the shape allows, N <= 32: it only has to name a working set -- the active-set
+ * method behind it, which produces the answer, and everything else are double.)
  * MPCQ_PRECISION_F32: mixed precision (round 5).  Storage and bulk arithmetic in float -- stage records (sensitivities, gaps, cost
  * gradients), Riccati factorisation on the matrix cores, gains, sweeps, RGP state --, the accuracy of double where cond(H) ~ 2e6
  * demands it: the iterate, the measurement and every difference that defines the QP are formed in double (as in F64), the shooting
@@ -89,7 +91,9 @@ typedef struct mpcq_tuning {
   double pin_ratio;     /* interior point -> working set: pinned where multiplier > pin_ratio x slack, (0, 1e3] (default 0.2) */
   double ipm_mu0;       /* complementarity of the interior start in units of the gradient scale, [1e-12, 1] (default 1e-4) */
   double ipm_margin;    /* interior start: distance from the bounds in units of their width, (0, 0.5) (default 0.1) */
-  double ipm_tol;       /* interior point -> active-set hand-over tolerance, [qp_tol, 1e-1] (default 1e-6 f64 / 1e-5 f32; f32: not below 1e-5) */
+  double ipm_tol;       /* interior point -> active-set hand-over tolerance, [qp_tol, 1e-1] (default 1e-6 f64 / 1e-5 f32; f32: not below 1e-5).
+                         * fp64 with N <= 32: the float interior point in front hands over at a complementarity of 3e-7 (compile-time), this one
+                         * is the tolerance of the double interior point that follows a float one that broke down */
   /* ---- since 0.4 */
   int32_t block_order;  /* launch order of a lockstep period: 0 automatic (quadrotors predicted expensive first when the batch exceeds
                            what the device holds at once), 1 never (workgroup p = quadrotor p), 2 always.  Results do not depend on it. */
