@@ -2592,7 +2592,11 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
       if (!handed) { broke = true; interior_start(); }
     }
   }
-  if (!handed) st = ipm_run<C>(m, S, A, Kb, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, it PF_PASS);
+  if (!handed) {   // (behind a float interior point that broke down -- possibly at its iteration cap -- the double one has its own budget)
+    int itd = broke ? 0 : it;
+    st = ipm_run<C>(m, S, A, Kb, L, m.polish_max > 0 ? m.ipm_tol : m.qp_tol, gm, itd PF_PASS);
+    it = broke ? it + itd : itd;
+  }
   bool need_roll = true;
   if (st == 0 && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
@@ -2604,7 +2608,9 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
       __syncthreads();
       PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL);
       PF_START(); adjoint<C>(m, S, A, L); PF_STOP(PF_ADJ);
-      st = ipm_run<C>(m, S, A, Kb, L, m.qp_tol, gm, it PF_PASS);
+      int itc = handed ? 0 : it;   // (the iterations of a float interior point are not charged to the double one that continues from its iterate)
+      st = ipm_run<C>(m, S, A, Kb, L, m.qp_tol, gm, itc PF_PASS);
+      it = handed ? it + itc : itc;
     }
   }
   if (need_roll) { PF_START(); rollout<C>(m, S, A, L, L.dx, L.z, true); PF_STOP(PF_ROLL); }   // state trajectory of the returned z

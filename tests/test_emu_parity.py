@@ -86,6 +86,13 @@ def test_emu_float_interior_point_breakdown_recovers():
         else:
             assert bd[fb].all() and bd[0].all()                # every fallback solve of this build, and the cold start, took the recovery path
     print("fallback solves / breakdowns:", seen)
+    # a float interior point that ends at its ITERATION CAP (12 here: it never reaches its negative tolerance and is still healthy at 12)
+    # leaves the double one its own budget (it used to find the common counter spent and report MPCQ_SOLVE_MAXITER)
+    make_c = lambda cfg: Engine(dataclasses.replace(cfg, qp_max_iter=12), lib_path=brk)
+    worst, hist, failed = pc.case_saturating_references(make_c, B=2, K=5)
+    # (the cold start of the two quadrotors needs more than 12 double iterations and reports the cap: expected, and counted)
+    assert failed <= 2 and worst < 1e-7, (worst, failed, hist)
+    assert sum(n for v, n in hist.items() if qp_fallback(v) and v % 1000 > 12) >= 4, hist   # 12 float iterations + the double solve behind them
 
 
 def test_emu_saturating_references_long_warm_attempts():
