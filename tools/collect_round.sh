@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_round.sh r5'): everything profiles/README.md lists for the final build of a round, in one call.
 R=${1:-r5}
 O=gpurun_out; mkdir -p $O
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > $O/${R}_gpu_tests.log
+python -m pytest tests -m gpu -x -q 2>&1 | grep -vE "RCCL version|HIP version|ROCm version|Hostname|Librccl path" | tail -6 > $O/${R}_gpu_tests.log
 bash tools/collect_profiles.sh ${R}_k20 --gpus 1 --steps 20 --warmup 5 > $O/collect_${R}_k20.log 2>&1
 python3 bench.py > $O/bench_${R}_default.json 2> $O/bench_${R}_default.err
 bash tools/collect_swarm_traffic.sh $R > $O/collect_${R}_swarm.log 2>&1
