@@ -1515,11 +1515,11 @@ template <typename TQ, typename PT> __device__ inline void dbg_dump(const DevMod
 #endif
 template <typename TQ> __device__ constexpr bool IPM_INCR() { return sizeof(TQ) == 8 || MPCQ_F32_IPM_INCR != 0; }
 template <typename C, typename TQ = typename C::T, bool GAB = C::GAB, typename M = DevModel<TQ>, typename PA = P<TQ>>
-MPCQ_COLD int ipm_run_regs(const M& m, P<TQ> S, PA A, P<TQ> Kb, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG, const TQ rd_floor = TQ(3e-4)) {
+MPCQ_COLD int ipm_run_regs(const M& m, P<TQ> S, PA A, P<TQ> Kb, const Lds& L, const TQ tol, const TQ gm, int& it PF_ARG, const TQ rd_floor = TQ(3e-4), const int cap = 0) {
   constexpr int N = C::N > 0 ? C::N : 1, nv = N * NU, R = (nv + 63) / 64;
   const int tid = lane_id();
   int status = 2;
-  const int maxit = m.qp_max_iter;
+  const int maxit = (cap > 0 && cap < m.qp_max_iter) ? cap : m.qp_max_iter;
   bool on[R];
   int ix[R], gi[R];
   TQ sl[R], su[R], ll[R], lu[R], g[R], rr[R];
@@ -2468,8 +2468,11 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
 #ifndef MPCQ_HYBRID_RD    // what it asks of its float dual residual, in units of the gradient scale (the float instances: 3e-4)
 #define MPCQ_HYBRID_RD 3e-4f
 #endif
+#ifndef MPCQ_HYBRID_MAXIT // its iteration cap (it needs 3 .. 10; one that stalls -- 1 fallback solve in 2e4 on the bench workload, the double one
+#define MPCQ_HYBRID_MAXIT 24   // stalls on the same QPs -- hands over what it has: the active-set method verifies what it ends on itself)
+#endif
 template <typename C, bool GAB = C::GAB>
-MPCQ_COLD bool ipm_float_stage(const DevModel<double>& m, P<double> S, P<double> A, P<double> Kb, const Lds& L, const double gm, int& it PF_ARG) {
+MPCQ_COLD int ipm_float_stage(const DevModel<double>& m, P<double> S, P<double> A, P<double> Kb, const Lds& L, const double gm, int& it PF_ARG) {
   constexpr int N = C::N, nv = N * NU, R = (nv + 63) / 64, RG = (N * VS + 63) / 64;
   const int tid = lane_id();
   Lds Lf = L;   // stage records: the double ones (offsets into A unchanged); QP workspace and gains: the float view
@@ -2500,16 +2503,19 @@ MPCQ_COLD bool ipm_float_stage(const DevModel<double>& m, P<double> S, P<double>
   for (int i = tid; i < (N + 1) * VS; i += 64) Sf[Lf.dx + i] = 0;   // (the float state trajectory is bookkeeping nobody reads)
   __syncthreads();
   int itf = 0;
-  const int stf = ipm_run_regs<C, float, GAB>(m, Sf, A, Kf, Lf, MPCQ_HYBRID_TOL, (float)gm, itf PF_PASS, MPCQ_HYBRID_RD);
+  const int stf = ipm_run_regs<C, float, GAB>(m, Sf, A, Kf, Lf, MPCQ_HYBRID_TOL, (float)gm, itf PF_PASS, MPCQ_HYBRID_RD, MPCQ_HYBRID_MAXIT);
   it += itf;
   // back to double: the smaller slack of an input is taken as it is, the point and the other slack follow from it (both positive, and
   // consistent with the bounds to double rounding -- what a continuation in double needs)
   float zf[R], slf[R], suf[R], llf[R], luf[R];
+  int sound = 1;   // every slack and multiplier finite and positive (an iteration that ended at its cap is handed over only then)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = tid + 64 * r, ii = i < nv ? i : 0;
     zf[r] = Sf[Lf.z + ii]; slf[r] = Sf[Lf.sl + ii]; suf[r] = Sf[Lf.su + ii]; llf[r] = Sf[Lf.ll + ii]; luf[r] = Sf[Lf.lu + ii];
+    if (!(slf[r] > 0.0f && slf[r] < 1e30f && suf[r] > 0.0f && suf[r] < 1e30f && llf[r] > 0.0f && llf[r] < 1e30f && luf[r] > 0.0f && luf[r] < 1e30f)) sound = 0;
   }
+  sound = wave_min(sound);
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -2525,7 +2531,7 @@ MPCQ_COLD bool ipm_float_stage(const DevModel<double>& m, P<double> S, P<double>
   if (tid < 3 * VS) S[L.wq + tid] = wqr;
   if (tid < VS) S[L.dx + tid] = dx0r;
   __syncthreads();
-  return stf == 0;
+  return (stf == 2 && !sound) ? 1 : stf;   // 0: at its tolerance | 2: at its iteration cap with a sound iterate | else: broken down
 }
 
 // Box-QP solve.  (1) Warm active-set attempt: the RTI iterate is persisted, so the working set of the
@@ -2588,7 +2594,8 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
   bool handed = false, broke = false;
   if constexpr (MPCQ_HYBRID_IPM != 0 && C::N > 0 && C::N * NU <= 128) {
     if (m.polish_max > 0) {
-      handed = ipm_float_stage<C>(m, S, A, Kb, L, gm, it PF_PASS);
+      const int stf = ipm_float_stage<C>(m, S, A, Kb, L, gm, it PF_PASS);
+      handed = stf == 0 || stf == 2;   // (2: stalled short of its tolerance at its iteration cap -- the working set it indicates is tried all the same)
       if (!handed) { broke = true; interior_start(); }
     }
   }
@@ -2598,11 +2605,14 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
     it = broke ? it + itd : itd;
   }
   bool need_roll = true;
-  if (st == 0 && m.polish_max > 0) {
+  // (st == 2: the double interior point at its iteration cap -- it stalls on about one fallback solve in 2e4 of the bench workload, the dual
+  //  residual lingering above its tolerance with the complementarity long there; the iterate is feasible and indicates a working set, and
+  //  what the active-set method settles on it has verified itself)
+  if ((st == 0 || st == 2) && m.polish_max > 0) {
     for (int i = tid; i < nv; i += 64) S[L.dza + i] = S[L.z + i];
     __syncthreads();
     int why2 = 0;
-    if (polish<C>(m, S, A, G, L, gm, passes, false, m.polish_max, why2 PF_PASS)) need_roll = false;
+    if (polish<C>(m, S, A, G, L, gm, passes, false, m.polish_max, why2 PF_PASS)) { need_roll = false; st = 0; }
     else {
       for (int i = tid; i < nv; i += 64) S[L.z + i] = S[L.dza + i];
       __syncthreads();

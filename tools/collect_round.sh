@@ -10,6 +10,7 @@ LB_F32=1 bash tools/collect_swarm_traffic.sh $R > $O/collect_${R}_swarm_f32.log 
 { python tools/profile_phases.py f64 40; python tools/profile_phases.py f32 40; } > $O/${R}_phase_cycles.txt 2>&1
 python tools/straggler_anatomy.py 200 > $O/${R}_straggler_anatomy.txt 2>&1
 { SOAK_EVERY=1 python tools/soak.py 1500 7; SOAK_EVERY=1 SOAK_NB=20 python tools/soak.py 600 7; SOAK_EVERY=1 SOAK_B=256 SOAK_N=50 SOAK_NB=50 python tools/soak.py 400 7; SOAK_B=8192 python tools/soak.py 600 7;
-  SOAK_EVERY=1 python tools/soak.py 1000 2026; SOAK_EVERY=1 python tools/soak.py 1000 3; } > $O/${R}_soak.txt 2>&1
+  SOAK_EVERY=1 python tools/soak.py 1000 2026; SOAK_EVERY=1 python tools/soak.py 1000 3;
+  for s in 11 12 13 14 15 16; do SOAK_PREC=f64 SOAK_EVERY=1 python tools/soak.py 800 $s; done; SOAK_PREC=f64 SOAK_EVERY=1 SOAK_NB=20 python tools/soak.py 600 21; } > $O/${R}_soak.txt 2>&1
 tools/microbench/chain_floor > $O/${R}_chain_floor.json 2>&1
 cat $O/${R}_gpu_tests.log; tail -3 $O/${R}_soak.txt

@@ -12,7 +12,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 B, N, nb = int(os.environ.get('SOAK_B', 1024)), int(os.environ.get('SOAK_N', 20)), int(os.environ.get('SOAK_NB', 10))
 refs = bench.workload(seed, 0, B, K + 10)
-for prec, name in ((0, "f64"), (1, "f32")):
+for prec, name in [pn for pn in ((0, "f64"), (1, "f32")) if os.environ.get("SOAK_PREC", pn[1]) == pn[1]]:   # SOAK_PREC=f64 | f32: that precision only
     e1, _ = bench.make_engine(B, N, nb, prec, 0, 0, seed, periods=K + 10, refs=refs)
     e2, _ = bench.make_engine(B, N, nb, prec, 0, 0, seed, periods=K + 10, refs=refs)
     bad = 0; fb = 0; low = 0; brk = 0
