@@ -236,12 +236,21 @@ def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps, dist=
     dt, dt_own, k_avg = lockstep_leg(e, n_sub, warmup, steps, dist)
     its, status = e.get_qp_iter(), e.get_status()
     st = e.get_tracking_stats()
+    groups = e.get_groups()
+    # one period of the WHOLE batch for the byte rates: the step kernel's own launch time by HIP events with one group; with several groups
+    # (a streaming batch: mpcq_tuning.groups automatic = 2) the events sit on group 0's launches, which cover B / groups quadrotors and share
+    # the device with the other groups' -- there the period is the host clock over the call (order and plant launches included: it errs low)
+    k_period = k_avg if groups == 1 else dt_own / steps
     out = {"config": name, "value": B * steps / dt_own, "unit": "control steps/s", "dtype": "f64" if prec == PRECISION_F64 else "f32",
            "batch": B, "horizon_nodes": N, "rgp_basis": nb, "steps": steps, "warmup": warmup, "preroll_periods": preroll,
-           "ms_per_step": 1e3 * dt_own / steps, "kernel_avg_ms": 1e3 * k_avg,
-           "algorithmic_gbs": algorithmic_bytes(N, nb, 8 if prec == PRECISION_F64 else 4) * B / k_avg / 1e9,
+           "ms_per_step": 1e3 * dt_own / steps, "kernel_avg_ms": 1e3 * k_avg, "groups": groups, "period_ms_for_byte_rates": 1e3 * k_period,
+           "algorithmic_gbs": algorithmic_bytes(N, nb, 8 if prec == PRECISION_F64 else 4) * B / k_period / 1e9,
            "mean_qp_passes": float(qp_passes(its).mean()), "failed": int(((status & 7) != 0).sum()),
            "rms_pos_m": float(np.sqrt(st[0] / (3 * max(st[2], 1))))}
+    if groups > 1:
+        out["groups_note"] = (f"mpcq_sim_steps runs this batch as {groups} contiguous groups, each advancing in lockstep on a HIP stream of its own: the tail of one "
+                              "group's launch (the device draining) is filled by the other's next launch; every quadrotor still advances `steps` periods "
+                              "between the two barriers; kernel_avg_ms = group 0's launches (B / groups quadrotors, sharing the device)")
     if prec == PRECISION_F32:
         out["low_accuracy_last_step"] = int((status == 8).sum())      # MPCQ_SOLVE_LOW_ACCURACY: refinement not converged (expected 0)
     if parity is not None:
@@ -254,12 +263,12 @@ def config_leg(name, refs, B, N, nb, prec, device, preroll, warmup, steps, dist=
     return out
 
 
-def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None, periods=1000, refs=None):
+def make_engine(B, N, nb, precision, device, first_index, seed, lib_path=None, periods=1000, refs=None, tune=None):
     """refs: (traj, lens) generated earlier (bench.workload forks worker processes: call it BEFORE this process touches the
     GPU and pass the result here)."""
     traj, lens = refs if refs is not None else workload(seed, first_index, B, periods)
     cfg = EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb),
-                       theta=[1.0, 0.1, 0.1], dt_pred=0.01, device=device, precision=precision)
+                       theta=[1.0, 0.1, 0.1], dt_pred=0.01, device=device, precision=precision, tune=tune)
     e = Engine(cfg, lib_path=lib_path)
     e.set_trajectories(traj, lens)
     e.sim_reset(np.tile(X0, (B, 1)))
@@ -587,8 +596,9 @@ def main():
         # HBM roofline of this leg (per GPU): algorithmic bytes over the launch time by HIP events; memory-side traffic from the rocprofv3 passes of this
         # configuration, attached only when they were taken on this build (source hash)
         sw_bytes = algorithmic_bytes(20, 10, 8) * SWARM
-        sw_roof = {"bound": "hbm", "achieved": sw_bytes / (leg["kernel_avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                   "algorithmic_bytes_per_launch": sw_bytes}
+        sw_period_ms = leg["period_ms_for_byte_rates"]      # (= kernel_avg_ms with one group; the period of the whole batch with several)
+        sw_roof = {"bound": "hbm", "achieved": sw_bytes / (sw_period_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                   "algorithmic_bytes_per_launch": sw_bytes, "period_ms": sw_period_ms, "groups": leg["groups"]}
         sw_roof["frac"] = sw_roof["achieved"] / HBM_PEAK_GBS
         import glob as _glob
         for tf in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_swarm_b8192.json"))):      # the profile taken on THIS build, if any
@@ -599,7 +609,7 @@ def main():
                 continue
             if tsw.get("source_sha16") == kernel_source_sha16():
                 sw_roof["traffic"] = tsw["hbm_bytes_per_launch"]
-                sw_roof["traffic_frac_of_peak"] = tsw["hbm_bytes_per_launch"] / (leg["kernel_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                sw_roof["traffic_frac_of_peak"] = tsw["hbm_bytes_per_launch"] / (sw_period_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 sw_roof["traffic_source"] = f"profiles/{os.path.basename(tf)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/large_batch.py 8192 20 10, same build)"
         swarm_out["roofline"] = sw_roof
         swarm_out.update({"config": f"BASELINE configs[3]: swarm of {SWARM * world} quadrotors, {SWARM} per GPU over {world} GPU(s)"
@@ -713,6 +723,24 @@ def main():
                                            "(step + plant) on its own; identical arithmetic and results, no per-period wait for the "
                                            "slowest instance of the batch"}
             e3.close()
+            # The same periods as lockstep launches of GROUPS of the batch (mpcq_tuning.groups): each group of B / G quadrotors advances in lockstep on
+            # its own stream, so a launch waits for the slowest quadrotor of its group only and the groups fill each other's waits.  Between
+            # `value` (one launch per period over the whole batch: what a controller fed by live measurements gets per tick) and free_running.
+            GL = 4
+            e4, _ = make_engine(B, N, nb, prec, local_rank, rank * B, args.seed, periods=periods, refs=refs, tune=dict(groups=GL))
+            e4.sim_run(args.preroll + args.warmup, n_sub, 5e-3)
+            e4.synchronize()
+            ta = time.perf_counter()
+            e4.sim_steps(KF, n_sub, 5e-3)
+            e4.synchronize()
+            tb = time.perf_counter()
+            x_g, w_g = e4.sim_get_state()
+            out["lockstep_groups"] = {"value": B * KF / (tb - ta), "unit": "control steps/s", "dtype": args.precision, "steps": KF, "groups": e4.get_groups(),
+                                      "ms_per_step": 1e3 * (tb - ta) / KF, "bitwise_equal_to_lockstep": bool(np.array_equal(x_g, x_lock) and np.array_equal(w_g, w_lock)),
+                                      "note": f"mpcq_sim_steps with mpcq_tuning.groups = {GL}: the batch as {GL} contiguous groups of {B // GL}, each advancing in lockstep "
+                                              "(one launch per period and group) on a HIP stream of its own; one call, every quadrotor advances `steps` periods; identical "
+                                              "results.  Not the headline: `value` keeps one launch per period over the whole batch"}
+            e4.close()
             alt = "f32" if args.precision == "f64" else "f64"
             e2, _ = make_engine(B, N, nb, PRECISION_F32 if alt == "f32" else PRECISION_F64, local_rank, 0, args.seed, periods=periods, refs=refs)
             e2.sim_steps(args.preroll + args.warmup, n_sub, 5e-3)

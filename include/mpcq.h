@@ -76,7 +76,7 @@ typedef enum mpcq_status {
  * workloads; results do not depend on them beyond rounding.  With MPCQ_TUNING=1 in the
  * environment, MPCQ_WARM_MAX, MPCQ_WARM_RETRY, MPCQ_FLIP_MAX, MPCQ_ABORT_PINS, MPCQ_ABORT_WRONG, MPCQ_POLISH_MAX,
  * MPCQ_PIN_RATIO, MPCQ_IPM_MU0, MPCQ_IPM_MARGIN, MPCQ_IPM_TOL, MPCQ_STAGE_MEM=lds|global|compact, MPCQ_GENERIC=1, MPCQ_BLOCK_ORDER,
- * MPCQ_SPLIT_PLANT=0|1 (the plant update between two lockstep periods as its own launch), MPCQ_KEV_STRIDE, MPCQ_VERBOSE=1 override
+ * MPCQ_SPLIT_PLANT=0|1 (the plant update between two lockstep periods as its own launch), MPCQ_GROUPS, MPCQ_KEV_STRIDE, MPCQ_VERBOSE=1 override
  * the corresponding field (measurement scripts only; without MPCQ_TUNING=1 the environment is not consulted). */
 typedef struct mpcq_tuning {
   int32_t warm_max;     /* passes of the warm active-set attempt, 1..64 (default 12; 6 in fp64 before round 4) */
@@ -84,7 +84,8 @@ typedef struct mpcq_tuning {
   int32_t flip_max;     /* changed bound states in a fallback solve above which the next warm attempt is skipped, 1..512; -1: never (default 2) */
   int32_t abort_pins;   /* warm attempt given up when its first pass pins this many inputs, 1..512; -1: never (default 10, N/2 for N > 20) */
   int32_t abort_wrong;  /* ... or a multiplier check finds this many wrong signs, 1..512; -1: never (default 9, 9N/20 for N > 20) */
-  int32_t polish_max;   /* active-set passes behind the interior point, 1..64; -1: none, interior point to qp_tol (default 16 f64 / 12 f32) */
+  int32_t polish_max;   /* active-set passes behind the interior point, 1..64; -1: none, interior point to qp_tol -- MPCQ_PRECISION_F64 only,
+                           refused with MPCQ_PRECISION_F32, whose answer comes from these passes (default 16 f64 / 12 f32) */
   int32_t stage_mem;    /* layout of the per-instance working set: 0 automatic, 1 all LDS, 2 per-stage records in global memory (L2),
                            3 compact (since 0.4: Riccati gains in global memory as well, <= 256 registers: more instances per CU) */
   int32_t generic_kernel; /* 1: the any-shape kernel instance even where a shape-specialised one exists */
@@ -97,7 +98,12 @@ typedef struct mpcq_tuning {
   /* ---- since 0.4 */
   int32_t block_order;  /* launch order of a lockstep period: 0 automatic (quadrotors predicted expensive first when the batch exceeds
                            what the device holds at once), 1 never (workgroup p = quadrotor p), 2 always.  Results do not depend on it. */
-  int32_t reserved0;    /* must be 0 */
+  /* ---- since 0.6 (0.4 / 0.5: a reserved field that had to be 0 = automatic) */
+  int32_t groups;       /* mpcq_sim_steps: the batch as this many contiguous groups, each advancing in lockstep on a HIP stream of its own,
+                           1..16; 0 automatic: 1 for a batch that is resident on the device as a whole, 2 for a larger one (the tail of one
+                           group's launch -- the device draining while the last workgroups finish -- is filled by the other group's next
+                           launch).  A call still ends with EVERY quadrotor K periods on and quadrotors are independent: results do not
+                           depend on it.  mpcq_step / mpcq_step_device_async (one period per call) are always one launch over the batch. */
 } mpcq_tuning;
 
 /* Engine configuration.  Replaces the constructor arguments of quad_optimizer
@@ -251,7 +257,7 @@ int mpcq_sim_control_periods(mpcq_engine* e, int32_t K, double control_dt, doubl
 int mpcq_sim_get_state(mpcq_engine* e, double* x /*[B,13]*/, double* w /*[B,4] or NULL*/);
 /* HIP-event time of the step-kernel launches of the last mpcq_sim_steps / mpcq_sim_run call (events recorded on
  * the engine's stream around every 4th launch, MPCQ_KEV_STRIDE=1 for every launch): total seconds of the timed
- * launches and their number. */
+ * launches and their number (mpcq_tuning.groups > 1: the launches of group 0, see mpcq_get_groups). */
 int mpcq_get_kernel_time(mpcq_engine* e, double* seconds, int32_t* launches);
 int mpcq_get_kernel_time_minmax(mpcq_engine* e, double* fastest_s, double* slowest_s);   /* of the same timed launches */
 /* diagnostic build only (libmpcq_prof.so, -DMPCQ_PROFILE): per-instance shader-cycle totals per phase of
@@ -261,6 +267,11 @@ int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out);
  * identity when no order is in use).  The reference solves one quadrotor per process (src/quad_opt.py:321-350) and has no
  * counterpart; results do not depend on the order. */
 int mpcq_get_block_order(mpcq_engine* e, int32_t* out);
+/* Since 0.6.  The number of groups mpcq_sim_steps runs this engine's batch in (mpcq_tuning.groups resolved: 1 = one launch per period
+ * over the whole batch).  With more than one group the launches mpcq_get_kernel_time reports are group 0's -- a launch over B / groups
+ * quadrotors that shares the device with the other groups' launches: per-period figures come from the caller's clock around the call.
+ * No counterpart in the reference (one quadrotor per process, src/quad_opt.py:321-350). */
+int mpcq_get_groups(mpcq_engine* e, int32_t* out);
 
 /* ---- tracking statistic (src/Visualiser.py:787-789,809-811,918), summed over this engine's
  * instances since the last reset: out[0]=sum |e_pos|^2, out[1]=sum |e_vel|^2, out[2]=steps,

@@ -29,6 +29,14 @@ int mpcq_minsnap_solve_order(const double* wp, int32_t n, const double* T, int32
 /* the linear stage of the reference's generator as published: estimateSegmentTimes (Nfabian, constant 6.5) + solveLinear, no scaling onto
  * the limits (the binary's nonlinear stage, an early-stopped Subplex run, is not reproducible: DESIGN.md section 6.1) */
 int mpcq_minsnap_linear(const double* wp, int32_t n, double v_max, double a_max, int32_t derivative_to_optimize, double* pieces);
+/* Since round 6.  Pieces (and cost) for GIVEN segment times and free vertex derivatives: the map the reference generator's nonlinear stage
+ * (mav_trajectory_generation::PolynomialOptimizationNonLinear<8>, behind src/trajectory_generation/TrajectoryGenerator.py:177-191) evaluates
+ * at every iterate of its optimiser.  d_free [n-2][3 axes][3] = velocity, acceleration, jerk at the interior waypoints (both ends at rest);
+ * cost (may be NULL) = the integral of the squared derivative_to_optimize over the trajectory, summed over x, y, z.  mpcq_minsnap_solve_order
+ * returns the pieces of the d_free that minimise that cost for the given T; the trajectories the reference logged are other points of the
+ * same family (tests/test_minsnap.py). */
+int mpcq_minsnap_from_derivatives(const double* wp, int32_t n, const double* T, const double* d_free, int32_t derivative_to_optimize,
+                                  double* pieces, double* cost);
 /* estimate + solve + uniform time scaling until the sampled peak speed / acceleration meet v_max / a_max */
 int mpcq_minsnap_generate(const double* wp, int32_t n, double v_max, double a_max, double* pieces);
 /* ... with the cost on derivative_to_optimize (mpcq_minsnap_generate = 4) */

@@ -54,6 +54,7 @@ SYMBOLS = [
     ("mpcq_get_kernel_time_minmax", ctypes.c_int, [_vp, _dp, _dp]),
     ("mpcq_debug_profile", ctypes.c_int, [_vp, _vp]),
     ("mpcq_get_block_order", ctypes.c_int, [_vp, _ip]),
+    ("mpcq_get_groups", ctypes.c_int, [_vp, _ip]),
     ("mpcq_get_tracking_stats", ctypes.c_int, [_vp, _dp]),
     ("mpcq_comm_unique_id", ctypes.c_int, [_vp]),
     ("mpcq_comm_init", ctypes.c_int, [_vp, ctypes.c_int32, ctypes.c_int32, _vp]),

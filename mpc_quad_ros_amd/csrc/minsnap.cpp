@@ -7,11 +7,13 @@
 // snap, with position fixed at every waypoint, velocity / acceleration / jerk continuous at the interior ones (and free
 // there) and zero at both ends; segment times from the distance / v_max / a_max ramp estimate, then stretched or shrunk
 // uniformly until the sampled speed and acceleration sit on their limits.  The binary itself (mav_trajectory_generation +
-// nlopt, no source in the reference tree) cannot run here and its exact objective is not recoverable from its outputs: a
-// least-squares fit of the segment times of this solver (snap, jerk or acceleration cost alike) to a trajectory the binary
-// produced -- the logged reference of outputs/python_simulation/data/traj0_v10_a10_gp2.pkl through
-// waypoints/user_defined_waypoints.csv -- leaves 0.6-1.2 m.  So this generator is the same trajectory FAMILY, not the
-// same trajectories; tests/test_minsnap.py pins its own properties (interpolation, continuity, optimality, limits, CSV).
+// nlopt, no source in the reference tree) cannot run here.  What its outputs say (tests/test_minsnap.py, round 6, on the three
+// logged references through waypoints/user_defined_waypoints.csv): they ARE chains of 7th-order pieces (a free per-piece fit leaves
+// the 6-decimal rounding of the samples), through the waypoints and C^3 to what the "%.6f" coefficients of its CSV allow -- i.e.
+// points of the family (segment times T, free vertex derivatives d_P) of mpcq_minsnap_from_derivatives below, which reproduces them
+// to that rounding; their d_P are NOT the optimum of the linear stage at their own T (off by up to 40 % of the velocity scale): the
+// binary's nonlinear stage moved times AND derivatives (an early-stopped Subplex run over both).  So this generator is the same
+// trajectory FAMILY, not the same trajectories.
 //
 // The unconstrained formulation: with d = (p, v, a, j) at both ends of a segment, coefficients c = A(T)^-1 d and cost
 // c' Q(T) c, so the total cost is a quadratic form in the vertex derivatives; the free ones (v, a, j at interior waypoints)
@@ -130,6 +132,28 @@ bool solve_axis(const double* p, int n, const double* T, double* coef, int order
   return true;
 }
 
+// one axis with GIVEN free derivatives dfree[3 (n - 2)] (v, a, j at the interior vertices): coefficients and cost d' M d
+void build_axis(const double* p, int n, const double* T, const double* dfree, double* coef, int order, double* cost) {
+  const int ns = n - 1;
+  double J = 0;
+  for (int s = 0; s < ns; ++s) {
+    double M[2 * ND][2 * ND], Ai[NC][NC], d[2 * ND];
+    segment_cost(T[s], M, Ai, order);
+    for (int a = 0; a < 2 * ND; ++a) {
+      const int v = s + a / ND, r = a % ND;
+      d[a] = r == 0 ? p[v] : ((v == 0 || v == n - 1) ? 0.0 : dfree[3 * (v - 1) + (r - 1)]);
+    }
+    for (int i = 0; i < NC; ++i) {
+      double c = 0;
+      for (int a = 0; a < 2 * ND; ++a) c += Ai[i][a] * d[a];
+      coef[s * NC + i] = c;
+    }
+    for (int a = 0; a < 2 * ND; ++a)
+      for (int b = 0; b < 2 * ND; ++b) J += d[a] * M[a][b] * d[b];
+  }
+  *cost = J;
+}
+
 // largest speed and acceleration magnitude over the trajectory, sampled every dt
 void limits(const double* coef, const double* T, int ns, double dt, double* vmax, double* amax) {
   double vm = 0, am = 0;
@@ -158,6 +182,7 @@ extern "C" {
 
 int mpcq_minsnap_solve_order(const double* wp, int32_t n, const double* T, int32_t derivative_to_optimize, double* pieces);
 int mpcq_minsnap_generate_order(const double* wp, int32_t n, double v_max, double a_max, int32_t derivative_to_optimize, double* pieces);
+int mpcq_minsnap_from_derivatives(const double* wp, int32_t n, const double* T, const double* d_free, int32_t derivative_to_optimize, double* pieces, double* cost);
 
 // Segment-time estimate from distance and the limits (velocity ramp: t = 2 d / v_max (1 + 6.5 v_max / a_max exp(-2 d / v_max))).
 int mpcq_minsnap_estimate_times(const double* wp, int32_t n, double v_max, double a_max, double* T) {
@@ -196,6 +221,36 @@ int mpcq_minsnap_solve_order(const double* wp, int32_t n, const double* T, int32
     for (int s = 0; s < ns; ++s)
       for (int i = 0; i < NC; ++i) pieces[(size_t)s * 33 + 1 + ax * NC + i] = c[(size_t)s * NC + i];
   }
+  return 0;
+}
+
+// The map the reference generator's NONLINEAR stage evaluates at every iterate (PolynomialOptimizationNonLinear<8>: nlopt varies the
+// segment times and the free vertex derivatives d_P; the polynomials and the cost follow from them): wp [n,3], T [n-1], d_free
+// [n-2][3 axes][3: velocity, acceleration, jerk] at the interior waypoints (both ends at rest) -> pieces [n-1,33] and, if cost is not
+// NULL, the integral of the squared derivative_to_optimize summed over the axes (solve_order returns the d_free that minimise it for
+// the given T).  The reference's logged trajectories are points of this family (tests/test_minsnap.py).
+int mpcq_minsnap_from_derivatives(const double* wp, int32_t n, const double* T, const double* d_free, int32_t derivative_to_optimize, double* pieces, double* cost) {
+  if (!wp || !T || !pieces || n < 2 || (n > 2 && !d_free) || derivative_to_optimize < 2 || derivative_to_optimize > 4) return -1;
+  const int ns = n - 1;
+  for (int s = 0; s < ns; ++s)
+    if (!(T[s] > 0)) return -1;
+  std::vector<double> p(n), c((size_t)ns * NC), df((size_t)3 * (n > 2 ? n - 2 : 0));
+  double total = 0;
+  for (int s = 0; s < ns; ++s) {
+    pieces[(size_t)s * 33] = T[s];
+    for (int i = 0; i < NC; ++i) pieces[(size_t)s * 33 + 25 + i] = 0.0;
+  }
+  for (int ax = 0; ax < 3; ++ax) {
+    for (int v = 0; v < n; ++v) p[v] = wp[v * 3 + ax];
+    for (int v = 0; v < n - 2; ++v)
+      for (int r = 0; r < 3; ++r) df[3 * v + r] = d_free[((size_t)v * 3 + ax) * 3 + r];
+    double J = 0;
+    build_axis(p.data(), n, T, df.data(), c.data(), derivative_to_optimize, &J);
+    total += J;
+    for (int s = 0; s < ns; ++s)
+      for (int i = 0; i < NC; ++i) pieces[(size_t)s * 33 + 1 + ax * NC + i] = c[(size_t)s * NC + i];
+  }
+  if (cost) *cost = total;
   return 0;
 }
 

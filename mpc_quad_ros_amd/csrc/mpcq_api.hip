@@ -14,6 +14,9 @@
 #include <vector>
 
 #define MPCQ_BUILDING_LIBRARY
+#ifndef MPCQ_AUTO_GROUPS   // groups of mpcq_sim_steps for a streaming batch when tune.groups = 0 (see EngineT::init)
+#define MPCQ_AUTO_GROUPS 2
+#endif
 #include "../../include/mpcq.h"
 #include "mpcq_kernels.hpp"
 
@@ -172,6 +175,7 @@ struct mpcq_engine {
   bool comm_borrowed = false;   // comm belongs to another engine of this process (mpcq_comm_share)
   int nranks = 1;
   double* d_stats5 = nullptr;
+  int n_groups = 1;              // groups of mpcq_sim_steps (mpcq_tuning.groups; EngineT::init)
   std::vector<hipEvent_t> kev;   // per-launch event pairs of the last sim_steps call
   double ktime = 0, kmin = 0, kmax = 0;   // HIP-event time of the timed step-kernel launches: total, fastest, slowest
   int klaunches = 0;
@@ -226,6 +230,10 @@ struct EngineT : mpcq_engine {
   int* d_order = nullptr;    // launch order of the lockstep periods (order_kernel); used when the batch exceeds what the device holds at once
   bool use_order = false;
   bool split_plant = false;   // the plant update between two lockstep periods as its own launch (streaming batches), see sim_steps
+  // mpcq_sim_steps with tune.groups > 1: the batch as n_groups contiguous groups, each advancing in lockstep on a stream of its own (sim_steps)
+  std::vector<hipStream_t> gstreams;
+  std::vector<hipEvent_t> gdone;
+  hipEvent_t gstart = nullptr;
   double* d_cmd = nullptr;   // [B*8] rotor thrusts, collective thrust, body rates (mpcq_get_command); also the chunk read-back
   size_t cmd_elems = 0;
   std::vector<T> hbuf;
@@ -241,6 +249,9 @@ struct EngineT : mpcq_engine {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     for (hipEvent_t ev : kev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : gdone) (void)hipEventDestroy(ev);
+    if (gstart) (void)hipEventDestroy(gstart);
+    for (hipStream_t gs : gstreams) if (gs != stream) (void)hipStreamDestroy(gs);
     if (stream) (void)hipStreamDestroy(stream);
     if (comm && !comm_borrowed && g_rccl.CommDestroy) g_rccl.CommDestroy(comm);
   }
@@ -298,7 +309,7 @@ struct EngineT : mpcq_engine {
     const bool env = tuning_env = getenv("MPCQ_TUNING") && atoi(getenv("MPCQ_TUNING")) != 0;
     if (!env) {   // advisor finding: a measurement script that forgets MPCQ_TUNING=1 would otherwise compare identical configurations
       static const char* const knobs[] = {"MPCQ_WARM_MAX", "MPCQ_WARM_RETRY", "MPCQ_FLIP_MAX", "MPCQ_ABORT_PINS", "MPCQ_ABORT_WRONG", "MPCQ_POLISH_MAX", "MPCQ_PIN_RATIO",
-                                          "MPCQ_IPM_MU0", "MPCQ_IPM_MARGIN", "MPCQ_IPM_TOL", "MPCQ_STAGE_MEM", "MPCQ_GENERIC", "MPCQ_BLOCK_ORDER", "MPCQ_KEV_STRIDE", "MPCQ_SPLIT_PLANT"};
+                                          "MPCQ_IPM_MU0", "MPCQ_IPM_MARGIN", "MPCQ_IPM_TOL", "MPCQ_STAGE_MEM", "MPCQ_GENERIC", "MPCQ_BLOCK_ORDER", "MPCQ_KEV_STRIDE", "MPCQ_SPLIT_PLANT", "MPCQ_GROUPS"};
       static bool warned = false;
       for (const char* k : knobs)
         if (!warned && getenv(k)) { fprintf(stderr, "mpcq: %s is set but MPCQ_TUNING=1 is not: the environment is ignored (use mpcq_config.tune)\n", k); warned = true; }
@@ -479,6 +490,22 @@ struct EngineT : mpcq_engine {
       // or as its own launch of one THREAD per quadrotor.  A resident batch waits for its slowest quadrotor, which the 2.5 us at
       // the head hardly move, and saves a launch; a streaming batch pays those cycles in throughput.
       split_plant = ienv("MPCQ_SPLIT_PLANT", (size_t)B > resident ? 1 : 0) != 0;
+      // Groups of mpcq_sim_steps (tune.groups; 0 = automatic).  A streaming batch ends every launch with a tail in which the device
+      // drains (the last workgroups finish one by one: 13 % of the resident-wave slots of a B = 8 192 launch stand empty,
+      // profiles/r6_pmc_icache_b8192.json) and the next period's launch cannot start before it has: cut into groups whose launches go to
+      // streams of their own, the tail of one group's period is filled by the other groups' launches.  Every group advances in lockstep,
+      // quadrotors are independent, a call still ends with every quadrotor K periods on: results do not depend on the grouping.
+      // A resident batch has no tail to fill (what its launch waits for is its slowest quadrotor): one group unless asked otherwise.
+      n_groups = ienv("MPCQ_GROUPS", tu.groups > 0 ? tu.groups : ((size_t)B > resident ? MPCQ_AUTO_GROUPS : 1));
+      if (n_groups < 1) n_groups = 1;
+      while (n_groups > 1 && B / n_groups < 8) n_groups -= 1;    // (a group holds at least one quadrotor of every launch-order class)
+      for (int g = 0; g < n_groups && n_groups > 1; ++g) {   // (group 0 runs on the engine's own stream: one hardware queue less)
+        hipStream_t gs = stream; hipEvent_t ev;
+        if (g > 0) HIP_TRY(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+        gstreams.push_back(gs);
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); gdone.push_back(ev);
+      }
+      if (n_groups > 1) HIP_TRY(hipEventCreateWithFlags(&gstart, hipEventDisableTiming));
     }
     kstep = ks[layout];
     krun = kr[layout];
@@ -561,19 +588,19 @@ struct EngineT : mpcq_engine {
     return 0;
   }
   int base_mode() const { return (cfg.flags & MPCQ_FLAG_STATIC_GP) ? mpcq::MODE_STATIC_GP : 0; }
-  // one lockstep period; ev_begin (if any) is recorded in front of the STEP kernel, behind the ordering launch, so that the event
-  // pairs of sim_steps time the step kernel alone
-  void launch_period(const mpcq::DevState<T>& s, int mode, hipEvent_t ev_begin = nullptr) {
+  // one lockstep period of the quadrotors [b0, b0 + nq) on stream `strm`; ev_begin (if any) is recorded in front of the STEP kernel, behind
+  // the ordering launch, so that the event pairs of sim_steps time the step kernel alone
+  void launch_period(const mpcq::DevState<T>& s, int mode, hipEvent_t ev_begin = nullptr, hipStream_t strm = nullptr, int b0 = 0, int nq = -1) {
+    if (!strm) strm = stream;
+    if (nq < 0) nq = B;
+    mpcq::DevState<T> so = s;
+    so.b0 = b0;
     if (use_order) {   // (reads qp_iter of the previous period; a permutation by construction whatever qp_iter holds: order_bin is total)
-      hipLaunchKernelGGL(mpcq::order_kernel, dim3(mpcq::ORD_CLASSES), dim3(mpcq::ORD_THREADS), mpcq::ORD_LDS, stream, (const int*)st.qp_iter, B, d_order);
-      mpcq::DevState<T> so = s;
-      so.order = d_order;
-      if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-      hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, so, mode);
-      return;
+      hipLaunchKernelGGL(mpcq::order_kernel, dim3(mpcq::ORD_CLASSES), dim3(mpcq::ORD_THREADS), mpcq::ORD_LDS, strm, (const int*)st.qp_iter + b0, nq, d_order + b0, b0);
+      so.order = d_order + b0;
     }
-    if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-    hipLaunchKernelGGL(kstep, dim3(B), dim3(64), lds_bytes, stream, m, s, mode);
+    if (ev_begin) (void)hipEventRecord(ev_begin, strm);
+    hipLaunchKernelGGL(kstep, dim3(nq), dim3(64), lds_bytes, strm, m, so, mode);
   }
   int launch_step(int mode) {
     HIP_TRY(hipEventRecord(ev0, stream));
@@ -685,6 +712,30 @@ struct EngineT : mpcq_engine {
     // (split_plant, see create): every update is a launch of the plant kernel.  Same arithmetic, same results either way.
     const bool split = split_plant;
     s2.run_x = d_xs; s2.run_steps = 1; s2.run_nsub = n_sub; s2.run_dt = sim_dt;
+    const int G = n_groups;
+    if (G > 1) {
+      // Groups (see init): group g = quadrotors [g0, g1), its K periods {order, step, plant} on gstreams[g], issued period by period round the
+      // groups so that the host feeds every queue.  The group streams start behind everything issued on the engine's stream and the
+      // engine's stream continues behind all of them.  Event pairs: group 0's launches (a launch of B / G quadrotors that shares the device).
+      HIP_TRY(hipEventRecord(gstart, stream));
+      for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(gstreams[g], gstart, 0));
+      const int per = ((B + G - 1) / G + 7) / 8 * 8;   // quadrotors per group (the last one takes what is left)
+      for (int k = 0; k < K; ++k)
+        for (int g = 0; g < G; ++g) {
+          const int g0 = g * per, g1 = std::min(B, g0 + per);
+          if (g0 >= g1) continue;
+          const bool timed_launch = g == 0 && k % stride == 0;
+          const int mode = mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode() | ((!split && k > 0) ? mpcq::MODE_PLANT_FIRST : 0);
+          launch_period(s2, mode, timed_launch ? kev[2 * (k / stride)] : nullptr, gstreams[g], g0, g1 - g0);
+          if (timed_launch) HIP_TRY(hipEventRecord(kev[2 * (k / stride) + 1], gstreams[g]));
+          if (split || k == K - 1)
+            hipLaunchKernelGGL(mpcq::plant_kernel<T>, dim3((g1 - g0 + 63) / 64), dim3(64), 0, gstreams[g], m, d_xs + (size_t)g0 * 13, st.w + (size_t)g0 * 4, n_sub, sim_dt, g1 - g0);
+        }
+      for (int g = 1; g < G; ++g) {
+        HIP_TRY(hipEventRecord(gdone[g], gstreams[g]));
+        HIP_TRY(hipStreamWaitEvent(stream, gdone[g], 0));
+      }
+    } else
     for (int k = 0; k < K; ++k) {
       const bool timed_launch = k % stride == 0;
       const int mode = mpcq::MODE_TRAJ | mpcq::MODE_POST | base_mode() | ((!split && k > 0) ? mpcq::MODE_PLANT_FIRST : 0);
@@ -864,9 +915,9 @@ const char* mpcq_last_error(void) { return g_err.c_str(); }
 #define MPCQ_SRC_ID "unknown"
 #endif
 #ifdef MPCQ_CHECKED
-const char* mpcq_version(void) { return "mpcq 0.5 (gfx950, CHECKED diagnostic build, source " MPCQ_SRC_ID ")"; }
+const char* mpcq_version(void) { return "mpcq 0.6 (gfx950, CHECKED diagnostic build, source " MPCQ_SRC_ID ")"; }
 #else
-const char* mpcq_version(void) { return "mpcq 0.5 (gfx950, source " MPCQ_SRC_ID ")"; }
+const char* mpcq_version(void) { return "mpcq 0.6 (gfx950, source " MPCQ_SRC_ID ")"; }
 #endif
 
 // binaries built against the 0.3 header (source callers get the header's inline, which passes their own sizeof): the 0.3 layout ends
@@ -899,8 +950,12 @@ int mpcq_create_sized(const mpcq_config* c_in, uint64_t cfg_size, mpcq_engine** 
     auto frange = [](double v, double lo, double hi) { return v == 0 || (v >= lo && v <= hi); };   // NaN fails both
     if (!irange(t.warm_max, 1, 64, false) || !irange(t.warm_retry, 1, 64, false) || !irange(t.flip_max, 1, 512, true) ||
         !irange(t.abort_pins, 1, 512, true) || !irange(t.abort_wrong, 1, 512, true) || !irange(t.polish_max, 1, 64, true) ||
-        !irange(t.stage_mem, 1, 3, false) || !irange(t.generic_kernel, 1, 1, false) || !irange(t.block_order, 1, 2, false) || t.reserved0 != 0)
+        !irange(t.stage_mem, 1, 3, false) || !irange(t.generic_kernel, 1, 1, false) || !irange(t.block_order, 1, 2, false) || !irange(t.groups, 1, 16, false))
       return fail(MPCQ_ERR_INVALID, "mpcq_config.tune: integer field out of range (see mpcq.h)");
+    // MPCQ_PRECISION_F32 answers from the active-set method (iterate and residuals in double); without it every fallback solve would return
+    // the float interior point's own answer with MPCQ_SOLVE_LOW_ACCURACY and the 1e-4 budget would not hold
+    if (c->precision == MPCQ_PRECISION_F32 && t.polish_max == -1)
+      return fail(MPCQ_ERR_INVALID, "mpcq_config.tune.polish_max = -1 (no active-set passes) is not available with MPCQ_PRECISION_F32");
     if (!frange(t.pin_ratio, 1e-300, 1e3) || !frange(t.ipm_mu0, 1e-12, 1.0) || !(t.ipm_margin == 0 || (t.ipm_margin > 0 && t.ipm_margin < 0.5)) ||
         !frange(t.ipm_tol, 1e-300, 1e-1))
       return fail(MPCQ_ERR_INVALID, "mpcq_config.tune: real field out of range (see mpcq.h)");
@@ -996,6 +1051,7 @@ int mpcq_debug_dump(mpcq_engine* e, double* out) {
 #endif
 /* diagnostic build only: per-instance phase cycle totals of the last step, [B][16] */
 int mpcq_debug_profile(mpcq_engine* e, unsigned long long* out) { ENTER(e); return e->get_prof(out); }
+int mpcq_get_groups(mpcq_engine* e, int32_t* out) { ENTER(e); if (!out) return fail(MPCQ_ERR_INVALID, "null argument"); *out = e->n_groups; return 0; }
 int mpcq_get_block_order(mpcq_engine* e, int32_t* out) { ENTER(e); if (!out) return fail(MPCQ_ERR_INVALID, "null argument"); return e->get_order(out); }
 
 int mpcq_comm_unique_id(void* id128) {

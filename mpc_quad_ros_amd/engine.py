@@ -162,6 +162,12 @@ class Engine:
         self._check(self.lib.mpcq_get_block_order(self.h, _lib.i(out)))
         return out
 
+    def get_groups(self):
+        """Groups mpcq_sim_steps runs the batch in (mpcq_tuning.groups resolved; 1 = one launch per period over the whole batch)."""
+        out = ctypes.c_int32()
+        self._check(self.lib.mpcq_get_groups(self.h, ctypes.byref(out)))
+        return out.value
+
     def get_time(self):
         t = ctypes.c_double()
         self._check(self.lib.mpcq_get_stats(self.h, ctypes.byref(t)))

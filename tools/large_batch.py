@@ -15,9 +15,12 @@ from mpc_quad_ros_amd.params import EngineConfig, hummingbird, rgp_basis_linspac
 B, N, nb, pre, K = (int(v) for v in (sys.argv[1:6] + ["8192", "20", "10", "600", "40"][len(sys.argv) - 1:]))
 refs = bench.workload(2026, 0, B, pre + K + 30)
 out = {"B": B, "N": N, "nb": nb, "preroll": pre, "steps": K, "runs": []}
-VARIANTS = {"identity": ("identity order", dict(block_order=1)), "sorted": ("cost-sorted order", dict(block_order=2)),
-            "global": ("layout: stage records in global memory, cost-sorted order", dict(stage_mem=2)),
-            "compact": ("layout: compact (gains in global memory, 256 registers), cost-sorted order", dict(stage_mem=3))}
+# (one group = one launch per period over the whole batch, as until round 5: the counter passes attribute their numbers per launch)
+VARIANTS = {"identity": ("identity order", dict(block_order=1, groups=1)), "sorted": ("cost-sorted order", dict(block_order=2, groups=1)),
+            "global": ("layout: stage records in global memory, cost-sorted order", dict(stage_mem=2, groups=1)),
+            "compact": ("layout: compact (gains in global memory, 256 registers), cost-sorted order", dict(stage_mem=3, groups=1))}
+for g in (1, 2, 3, 4, 6, 8, 16):      # mpcq_tuning.groups: the batch as g groups, each in lockstep on its own stream (automatic layout and order)
+    VARIANTS[f"g{g}"] = (f"{g} group(s)", dict(groups=g))
 which = os.environ.get("LB_VARIANTS", "identity,sorted").split(",")
 for name, tune in (VARIANTS[w] for w in which):
     e = Engine(EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), tune=tune, precision=1 if os.environ.get("LB_F32") else 0))

@@ -14,7 +14,7 @@ os.environ["MPCQ_TUNING"] = "1"     # the library reads MPCQ_STAGE_MEM / MPCQ_GE
 lib = ctypes.CDLL(os.path.abspath(sys.argv[1]))
 dp = ctypes.POINTER(ctypes.c_double)
 ip = ctypes.POINTER(ctypes.c_int32)
-lib.mpcq_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+lib.mpcq_create_sized.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]   # (the exported mpcq_create reads the 0.3 layout only)
 lib.mpcq_set_trajectories.argtypes = [ctypes.c_void_p, dp, ip, ctypes.c_int32]
 lib.mpcq_sim_reset.argtypes = [ctypes.c_void_p, dp]
 lib.mpcq_sim_steps.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double]
@@ -36,7 +36,7 @@ for mem in ("lds", "global"):
         cfg = EngineConfig(batch=B, N=N, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb))
         c = cfg.to_c()
         h = ctypes.c_void_p()
-        assert lib.mpcq_create(ctypes.byref(c), ctypes.byref(h)) == 0
+        assert lib.mpcq_create_sized(ctypes.byref(c), ctypes.sizeof(c), ctypes.byref(h)) == 0
         lib.mpcq_set_trajectories(h, traj.ctypes.data_as(dp), lens.ctypes.data_as(ip), traj.shape[1])
         lib.mpcq_sim_reset(h, x0.ctypes.data_as(dp))
         ws, bad = [], 0

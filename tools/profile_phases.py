@@ -17,6 +17,8 @@ NAMES = ["load", "shoot_x", "shoot_s", "factor", "fwd", "bwd", "adjoint", "rollo
 FINE = {11: "fwd: loads/shift", 12: "fwd: K Dx chain", 13: "fwd: broadcast", 14: "fwd: A Dx chain"}
 if os.environ.get("PROF_MODE") == "serial":   # library built with -DMPCQ_PROFILE_SERIAL (PROF_LIB names it): the single-lane blocks and the parts of the post phase
     FINE = {11: "load: plant RK4 (lane 0)", 12: "post: nominal RK4 (lane 0)", 13: "post: drag, stats (lane 0)", 14: "post: RGP regress"}
+if os.environ.get("PROF_MODE") == "other":   # library built with PROF_EXTRA=-DMPCQ_PROFILE_OTHER (PROF_LIB names it): what lies between the bracketed phases (fp64)
+    FINE = {11: "other: shooting -> QP", 12: "other: pass set-up", 13: "other: factor -> sweep", 14: "other: ratio test, multipliers, step", 15: "other: QP -> full step"}
 if os.environ.get("PROF_MODE") == "fac":   # library built with PROF_EXTRA=-DMPCQ_PROFILE_FAC: slots 11..15 split the factorisation
     FINE = {11: "fac: tile products", 12: "fac: LDS hand-over", 13: "fac: 4x4 LDL^T", 14: "fac: solves + stores", 15: "fac: P update + loop"}
 
@@ -53,7 +55,7 @@ def main():
     for k, n in FINE.items():
         if mean[k] > 0:
             print(f"  {n:22s} {mean[k]:12.0f} {mxs[k]:20.0f}")
-    if mean[14] > 0 and os.environ.get("PROF_MODE") not in ("fac", "serial"):   # active-set statistics of the fp64 path (diagnostic counters of polish())
+    if mean[14] > 0 and os.environ.get("PROF_MODE") not in ("fac", "serial", "other"):   # active-set statistics of the fp64 path (diagnostic counters of polish())
         tot = acc.sum(axis=0)
         print(f"factorisations per quad-step {mean[14]:.3f} (slowest quad of a launch: {mxs[14]:.2f}); stages visited per factorisation {tot[13] / tot[14]:.1f}; "
               f"pins per quad-step {mean[11]:.3f}, passes with a release {mean[12]:.3f}, with both {mean[15]:.3f}")
