@@ -61,22 +61,23 @@ def latency_roofline(e, n_sub, N, launches=20):
     measured chain of one sweep stage) -- both from tools/microbench/chain_floor.hip (registers only, nothing but the chain;
     profiles/r5_chain_floor.json) -- + the non-QP phases at their measured cost.  The interior-point iterations of a fallback solve
     of the fp64 instances run in float (csrc/mpcq_kernels.hpp ipm_float_stage): their factorisation and their three sweeps are priced
-    with the float chains, unless the work word says the float interior point broke down (then everything is double).  `launches`
+    with the float chains -- exactly the iterations the engine reports as float in its work word (mpcq_get_qp_work bits 27..31; advisor finding of
+    round 5: the pricing used to be inferred from the shape).  `launches`
     further lockstep periods, one call each, with the work counters (mpcq_get_qp_work) and the launch time read back after every one."""
     try:
         with open(os.path.join(ROOT, "profiles", "r5_chain_floor.json")) as fh:
             fl = json.load(fh)
     except (OSError, ValueError):
         return None
-    float_ipm = e.cfg.precision == 0 and 4 * N <= 128      # the shapes whose interior point runs in registers (ipm_run_regs)
-    floor, got, slow_fac, slow_ipm = [], [], [], []
+    floor, got, slow_fac, slow_ipm, float_any = [], [], [], [], False
     for _ in range(launches):
         e.sim_steps(1, n_sub, 5e-3)
         kt, _kl = e.get_kernel_time()
         fac, swp = e.get_qp_work()
         # interior-point iterations of a solve: a fallback solve executes 2 it + 2 (+1) more sweeps than factorisations (solve_qp's work count)
         ipm = np.where(qp_fallback(e.get_qp_iter()), np.maximum(0, (swp - fac - 2) // 2), 0)
-        ipm_f = np.where(e.get_qp_float_breakdown(), 0, ipm) if float_ipm else np.zeros_like(ipm)
+        ipm_f = np.minimum(e.get_qp_float_iterations(), ipm)      # those the engine says it ran in float (the work word, bits 27..31): priced with the float chains
+        float_any = float_any or bool(ipm_f.any())
         chain_ns = ((fac - ipm_f) * fl["factor_stage_chain_ns"] + ipm_f * fl["factor_stage_chain_f32_ns"]
                     + (swp - 3 * ipm_f) * fl["sweep_stage_chain_ns"] + 3 * ipm_f * fl["sweep_stage_chain_f32_ns"]) * N
         floor.append(float(chain_ns.max()) * 1e-6 + NONQP_CHAIN_US * 1e-3)
@@ -86,7 +87,7 @@ def latency_roofline(e, n_sub, N, launches=20):
         slow_ipm.append(int(ipm[b]))
     return {"bound": "dependent-chain latency of the slowest quadrotor of a launch", "floor_ms": float(np.mean(floor)), "achieved_ms": float(np.mean(got)),
             "frac": float(np.mean(floor) / np.mean(got)), "launches": launches, "slowest_quad_factorisations_mean": float(np.mean(slow_fac)),
-            "slowest_quad_interior_point_iterations_mean": float(np.mean(slow_ipm)), "interior_point_iterations_in_float": bool(float_ipm),
+            "slowest_quad_interior_point_iterations_mean": float(np.mean(slow_ipm)), "interior_point_iterations_in_float": bool(float_any),
             "factor_stage_chain_ns": fl["factor_stage_chain_ns"], "sweep_stage_chain_ns": fl["sweep_stage_chain_ns"],
             "factor_stage_chain_f32_ns": fl["factor_stage_chain_f32_ns"], "sweep_stage_chain_f32_ns": fl["sweep_stage_chain_f32_ns"],
             "non_qp_phases_us_measured": NONQP_CHAIN_US,

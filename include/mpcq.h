@@ -183,10 +183,12 @@ int mpcq_get_status(mpcq_engine* e, int32_t* out);               /* solve() stat
  * on/off their bounds (the next solve skips the warm attempt); qp_iter / 100000: why the warm attempt ended
  * (MPCQ_WARM_*), 0 when it succeeded or there was none (cold start). */
 int mpcq_get_qp_iter(mpcq_engine* e, int32_t* out);
-/* What the last solve of every quadrotor executed, out [B]: Riccati factorisations (bits 0..14; resumed ones count as whole)
- * | matrix-vector sweeps over the horizon (bits 16..31).  Bit 15 (fp64 instances): the float interior point of a
- * fallback solve broke down and the double one ran from the start (a diagnostic: the answer comes from the double active-set
- * method either way).  The dependent chains of these are what a lockstep launch lasts
+/* What the last solve of every quadrotor executed, out [B] (read as unsigned): Riccati factorisations (bits 0..14; resumed ones count
+ * as whole) | matrix-vector sweeps over the horizon (bits 16..26, saturating) | since 0.6, bits 27..31: how many of the interior-point
+ * iterations ran in float (fp64 instances whose interior point iterates in float, N <= 32 on a shape-specialised instance: all of a
+ * fallback solve's, unless bit 15 is set; 0 everywhere else -- a latency model prices exactly these with the float chains).  Bit 15 (fp64
+ * instances): the float interior point of a fallback solve broke down and the double one ran from the start (a diagnostic: the answer
+ * comes from the double active-set method either way).  The dependent chains of these are what a lockstep launch lasts
  * (bench.py `latency_roofline`).  acados reports sqp_iter / qp_iter through get_stats (src/quad_opt.py:337 reads time_tot only). */
 int mpcq_get_qp_work(mpcq_engine* e, int32_t* out);
 #define MPCQ_WARM_BUDGET 1    /* pass budget (warm_max / warm_retry) exhausted */

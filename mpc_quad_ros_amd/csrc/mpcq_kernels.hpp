@@ -47,6 +47,21 @@ namespace mpcq {
 #ifndef MPCQ_ROLL_RK
 #define MPCQ_ROLL_RK 1
 #endif
+// Round-6 restructurings of the glue between the phases: built, measured on the MI355X (tools/r6_ab.sh, tools/r6_ab4.sh,
+// profiles/r6_glue_ab.txt) and NOT in the product -- the step kernel sits at the edge of the register file (256 VGPRs, 160+ SGPR spills),
+// and what an edit saves in instructions the allocation it shifts gives back:
+//   MPCQ_G_SHFL = 1     GP sums of a stage's three lanes through ds_bpermute instead of LDS memory + two barriers      0 .. - 2 %
+//   MPCQ_G_DXBATCH = 1  gap operand of a working-set pass: the global loads of a block issued together                 0 .. - 2 %
+//   (tools/experiments/r6_glue_restructurings.patch:)  the new iterate kept in registers between the full step and the cost: - 7 %
+//   (20 KB more code, SGPR spills 190 -> 340); the compact fp64 layout without X in LDS -- 22.1 instead of 24.3 KB, SEVEN quadrotors
+//   per CU: + 0.5 %, a seventh resident wavefront buys nothing once the groups fill the launch tails; fused ratio-test / step passes: 0;
+//   the solver's previous-period record fetched with the load phase instead of in front of the QP: - 1 %.
+#ifndef MPCQ_G_SHFL
+#define MPCQ_G_SHFL 0
+#endif
+#ifndef MPCQ_G_DXBATCH
+#define MPCQ_G_DXBATCH 0
+#endif
 #if MPCQ_ROLL_RK
 #define MPCQ_RK_LOOP _Pragma("clang loop unroll(disable)")
 #else
@@ -294,7 +309,7 @@ struct DevState {
   const int* tlen;
   int* status;
   int* qp_iter;
-  int* qp_work;     // [B] what the last solve executed: factorisations (bits 0..14) | float interior point broke down (bit 15) | vector sweeps << 16 (mpcq_get_qp_work)
+  int* qp_work;     // [B] what the last solve executed: factorisations (bits 0..14) | float interior point broke down (bit 15) | vector sweeps (bits 16..26) | interior-point iterations run in float (bits 27..31) (mpcq_get_qp_work)
   int* finished;    // [B] trajectory finished (src/mpc_controller_node.py:374), sticky until new trajectories / reset
   TQ* stage;        // [B][Lds::gtotal] per-instance stage records (GAB layouts only)
   double* run_x;    // [B][13] plant states of the free-running closed loop (MODE_RUN; aliases x_meas)
@@ -314,10 +329,11 @@ struct DevState {
 struct Lds {
   int X, U, x0, pre, dbytes;
   int zd, dxd;               // mixed precision (TQ = float): the QP solution and its state trajectory in double (refined against fp64 residuals)
+  int curv;                  // mixed precision: (B' P B)_aa of every input from the last working-set factorisation (what releasing a pinned input would move it by: polish_mixed)
   int AB, c, qv, r0, lb, ub, alpha, basis, wq;
   int z, sl, su, ll, lu, grad, vin, dza, dz, rho, act, rt, dx, Dx, K, Linv, sF, sT, stv;
   int sub, rgp, qtotal;
-  int gab, zb, gx, gtotal;   // stage data (AB'', c, qv) in global memory? ; LDS zero block ; GP exchange scratch ; global elements per instance
+  int gab, zb, gx, gtotal;   // stage data (AB'', c, qv) in global memory? ; LDS zero block ; GP exchange scratch (MPCQ_G_SHFL = 0 only) ; global elements per instance
   int gk;                    // Riccati gains K, Lambda^-1 in the global record as well, and r0 / lb / ub inside the union (written behind the shooting)
   int mrow;                  // multiplier rows (always global): per stage 4 rows [M_a(13) | F_uu row(4) | gt_a | pad 2]
   int pst;                   // cost-to-go of every stage (always global): [P_i as accumulator tile (256) | p_i (16)]
@@ -349,13 +365,13 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab, int mixed = 0)
     L.c = gtake(N * VS);
     L.qv = gtake((N + 1) * VS);
     L.zb = take(VS);
-    L.gx = take(22 * 8);   // 21 lane triples + the idle lane 63
+    L.gx = MPCQ_G_SHFL ? 0 : take(22 * 8);   // 21 lane triples + the idle lane 63
   } else {
     L.AB = take(N * ABS + VS);
     L.c = take(N * VS);
     L.qv = take((N + 1) * VS);
     L.zb = L.AB + N * ABS;
-    L.gx = L.AB;   // exchange scratch of shoot_states: AB'' is not written before shoot_sens
+    L.gx = L.AB;   // (MPCQ_G_SHFL = 0: exchange scratch of shoot_states; AB'' is not written before shoot_sens)
   }
   L.mrow = gtake(N * MROW * NU);
   L.pst = gtake(((N + PSTEP - 1) / PSTEP) * PST);   // one tile per PSTEP stages (pst_first)
@@ -363,6 +379,7 @@ __host__ __device__ inline Lds lds_layout(int N, int nb, int gab, int mixed = 0)
   L.alpha = take(3 * nb);
   L.basis = take(3 * nb);
   L.wq = take(3 * VS);   // stage / terminal state weights in internal order, input weights
+  L.curv = mixed ? take(nv) : 0;
   const int u0 = o;  // ---- union: shooting records | QP workspace | RGP workspace
   L.sub = u0;
   const int sub_end = u0 + al4(N * SUBS);
@@ -687,7 +704,7 @@ template <typename T> struct QC {
 // f(x,u) of the OCP model (src/quad_opt.py:186-251 in the reference); when `sub` != nullptr also
 // writes the record the sensitivity pass needs: q(4) r(3) | d vdot/dq (3x4) | d vdot/dv (3x3) | R[:,2]  (SUB_*).
 // GP term: m_d(s) = sum_j alpha_dj sf2 exp(-(s - X_j)^2 L2inv / 2), alpha = Kx^-1 mu.
-// gd >= 0: this lane sums only GP axis gd and the three lanes of a stage exchange the sums through gx (LDS).
+// gd >= 0: this lane sums only GP axis gd (lanes l - gd .. l - gd + 2 hold the three axes of a stage) and the three exchange their sums.
 template <typename T, typename TG, typename PA, typename PB, typename PS, typename PG = TG*>
 __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const TG* sf2, const T* x, const T* u,
                                   PA alpha, PB basis, T* f, PS sub, int gd = -1, PG gx = nullptr) {
@@ -736,12 +753,22 @@ __device__ inline void model_eval(const QC<T>& m, int nb, const TG* L2inv, const
         s0 += k;
         s1 -= k * dlt;
       }
+#if MPCQ_G_SHFL
+      // the three lanes of a stage exchange their sums through the LDS crossbar (ds_bpermute: no LDS memory, no barrier; lane 63, which has
+      // no partners, reads lanes 0 / 1 and is not used)
+      const int l0 = lane_id() - gd;
+      const TG e0 = s0, e1 = s1 * l2;
+      CK_EXEC_FULL(5);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { mg[d] = (T)__shfl(e0, l0 + d); mp[d] = (T)__shfl(e1, l0 + d); }
+#else
       gx[gd] = s0;
       gx[3 + gd] = s1 * l2;
       __syncthreads();
 #pragma unroll
       for (int d = 0; d < 3; ++d) { mg[d] = (T)gx[d]; mp[d] = (T)gx[3 + d]; }
       __syncthreads();
+#endif
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) f[7 + i] += R[3 * i] * mg[0] + R[3 * i + 1] * mg[1] + R[3 * i + 2] * mg[2];
@@ -889,7 +916,7 @@ MPCQ_PHASE void shoot_states(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> 
   const TS h = (TS)m.h;
   // with the GP in the model the three axis sums (nb exps each) of a stage go to three neighbouring lanes
   const int per = gp ? 3 : 1, lanes_used = gp ? 63 : 64, spr = lanes_used / per;   // stages per round
-  P<TQ> gx = S + (L.gx + (lane / 3) * 8);   // LDS exchange scratch
+  P<TQ> gx = S + (L.gx + (lane / 3) * 8);   // LDS exchange scratch (MPCQ_G_SHFL = 0 only)
   for (int base = 0; base < N; base += spr) {
     const int il = lane / per, d = lane - il * per;
     const bool valid = lane < lanes_used && base + il < N;
@@ -1348,6 +1375,12 @@ MPCQ_PHASE bool riccati_factor(const M& m, P<TQ> S, PA A, P<TQ> Kb, const Lds& L
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int q = 0; q <= a; ++q) Lm[a][q] = bc(acc2[in_s<TQ>(a)], 16 * in_h<TQ>(a) + 10 + q);
+    if constexpr (polish && sizeof(TQ) == 4) {   // mixed precision: the curvature B'PB of every input on this working set (polish_mixed's report)
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) S[L.curv + i * NU + a] = Lm[a][a];
+      }
+    }
     // hand rows 10..13 over to the stage-Hessian lanes through LDS
     if (sizeof(TQ) == 4) {
       if (h >= 2) {   // h = 2: registers 2,3 = rows 10,11 ; h = 3: registers 0,1 = rows 12,13
@@ -1825,6 +1858,28 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
 #endif
       }
       __syncthreads();
+#if MPCQ_G_DXBATCH
+      // (the gaps come from the stage records -- global memory in the GAB layouts: the loads of a block are issued together, one memory
+      //  round trip per block instead of one per 64 elements; the pad slots 13..15 of c are zero, shoot_sens)
+      constexpr int CB = 5;
+      for (int base = 0; base < N * VS; base += 64 * CB) {
+        TQ cv[CB];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) { const int it = base + 64 * u + tid; cv[u] = A[L.c + (it < N * VS ? it : 0)]; }
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+          const int it = base + 64 * u + tid, i = it >> 4, r = it & 15;
+          if (it >= N * VS) continue;
+          TQ v = cv[u];
+          if (nact > 0 && r < NX) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j)
+              if (S[L.act + i * NU + j] != TQ(0)) v += A[L.AB + i * ABS + r * ABW + 10 + j] * S[L.z + i * NU + j];
+          }
+          S[L.Dx + it] = v;
+        }
+      }
+#else
       for (int it = tid; it < N * VS; it += 64) {
         const int i = it >> 4, r = it & 15;
         TQ v = 0;
@@ -1838,6 +1893,7 @@ MPCQ_PHASE bool polish(const DevModel<TQ>& m, P<TQ> S, P<TQ> A, P<TQ> G, const L
         }
         S[L.Dx + it] = v;
       }
+#endif
       __syncthreads();
       PF_START();
       TQ gfac = 0;
@@ -2246,7 +2302,7 @@ MPCQ_PHASE void adjoint64_bwd(const DevModel<float>& m, P<double> D, P<float> S,
 // judged on the double values.  A warm solve without a change of the working set costs one factorisation and three sweeps.
 // On success D[L.zd], D[L.dxd] hold the solution, S[L.z] its float image.
 #ifndef MPCQ_MIXED_TOLC
-#define MPCQ_MIXED_TOLC 1e-5
+#define MPCQ_MIXED_TOLC 1e-6   // (1e-5 until round 6: see the weak-multiplier note in polish_mixed; 1e-6 costs nothing measurable)
 #endif
 template <typename C, bool GAB = C::GAB>
 MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, P<float> A, P<float> Kb, const Lds& L, float gm, int& passes, const bool warm,
@@ -2265,11 +2321,14 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
     }
   }
   double tolm = 1e-12 * (double)gm;   // multiplier sign test: the multipliers come from double residuals (the fp64 method: 64 eps gm = 7e-15 gm)
-  // The anti-cycling rule below loosens the sign test by factors of 100.  Once is the degenerate input it was made for (a multiplier of zero
-  // to rounding, 1e-10 of the gradient scale).  Beyond that the working set keeps cycling because the float factorisation is no contraction
-  // any more (predictions that tumble, gradient scale above 1e6): what the method then settles on can hold a wrong-signed multiplier of any
-  // size -- seen on the reference's own traj2_v10_a10_gp2 flight, steps 116 and 120: 0.13 / 0.43 of full thrust off with status 0 -- so it
-  // is reported (MPCQ_SOLVE_LOW_ACCURACY), never returned as a clean solve.
+  // The anti-cycling rule below loosens the sign test by factors of 100.  It was made for a degenerate input (a multiplier of zero to
+  // rounding: released, its Newton step leaves it on its bound to rounding, pinned again, ...), where any working set of the cycle is the
+  // answer.  It also fires when the working set cycles because the float factorisation is no contraction any more (predictions that
+  // tumble, gradient scale above 1e6) -- and what the method then settles on can hold a wrong-signed multiplier of any size (the reference's
+  // own traj2_v10_a10_gp2 flight, steps 116 and 120: 0.13 / 0.43 of full thrust off, status 0 until round 6).  So a solve that settles
+  // under a loosened test says what the multipliers it ignores are worth: releasing pinned input a alone moves it by lambda_a over its
+  // curvature R_aa + (B'PB)_aa (S[L.curv], left by the factorisation of this working set); beyond tol_c the solve is reported
+  // (MPCQ_SOLVE_LOW_ACCURACY), never returned as a clean one.
   int loosened = 0;
   // bound proximity of a pin and what a refinement may leave behind, in units of full thrust: the iterate is double, so neither needs the
   // float-sized 1e-6 of the first version
@@ -2457,13 +2516,38 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
     }
     released = false;
     if (corrected && full) {
-      if (dzm <= tol_c) { settled = true; passes += 1; break; }   // (the forward sweep has taken the trajectory along)
+      if (dzm <= tol_c) {   // (the forward sweep has taken the trajectory along)
+        // The multipliers behind this were evaluated in FRONT of the correction, at a point off by dzm: that moves the multiplier of pinned input a
+        // by about its curvature R_aa + (B'PB)_aa times dzm (S[L.curv]), enough to hide the wrong sign of a weak one -- an input that belongs a few
+        // 1e-5 inside its bound stays pinned, the solve settles 1e-5 off with status 0 (round 6, every solve of the bench workload against the
+        // fp64 engine: 6 in 1.7 M, idling quadrotors, tools/f32_audit.py).  A solve with such a multiplier takes one more trip: the residual
+        // at the refined point shows its sign.
+        int weak = 0;
+        if (nact > 0)
+          for (int i = tid; i < nv; i += 64) {
+            const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
+            if (a != TQ(0) && (a < 0 ? -g : g) > -8.0f * (S[L.curv + i] + S[L.wq + 2 * VS + (i & 3)]) * (float)dzm) weak = 1;
+          }
+        if (nact > 0) weak = wave_max(weak);
+        if (!weak) { settled = true; passes += 1; break; }
+      }
       gF_prev = gF; dz_prev = dzm;
     }
     __syncthreads();
   }
   __syncthreads();
-  if (settled && loosened > 1) converged = 0;   // (see `loosened` above)
+  if (settled && loosened > 0) {   // (see `loosened` above)
+    float est = 0;
+    for (int i = tid; i < nv; i += 64) {
+      const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
+      const float v = a < 0 ? -g : g;
+      if (a != TQ(0) && v > 0.0f) est = tmax(est, v / (S[L.curv + i] + S[L.wq + 2 * VS + (i & 3)]));
+    }
+    est = wave_max(est);
+    // (handing such a solve to the next stage instead -- interior point, then this method again -- was tried: it rescued none and turned
+    //  solves that were within the budget into MPCQ_SOLVE_MAXITER)
+    if (!(est <= (float)tol_c)) converged = 0;
+  }
   if (settled)
     for (int i = tid; i < nv; i += 64) {
       const TQ a = S[L.act + i];
@@ -2615,9 +2699,11 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
   DBG_DUMP(1, 640, S, L.grad, N * VS); DBG_DUMP(1, 1024, S, L.dx, (N + 1) * VS); DBG_DUMP(1, 1536, A, L.AB, N * ABS > 2500 ? 2500 : N * ABS);
   // shapes whose interior point runs in registers: its iterations to the hand-over in float (ipm_float_stage); broken down -> in double from the start
   bool handed = false, broke = false;
+  int fit = 0;   // interior-point iterations executed in float (reported in the work word: what a latency model prices with the float chains)
   if constexpr (MPCQ_HYBRID_IPM != 0 && C::N > 0 && C::N * NU <= 128) {
     if (m.polish_max > 0) {
       const int stf = ipm_float_stage<C>(m, S, A, Kb, L, gm, it PF_PASS);
+      fit = it;                        // (the interior point's iterations so far are the float ones)
       handed = stf == 0 || stf == 2;   // (2: stalled short of its tolerance at its iteration cap -- the working set it indicates is tried all the same)
       if (!handed) { broke = true; interior_start(); }
     }
@@ -2662,7 +2748,8 @@ MPCQ_PHASE int solve_qp(const DevModel<TQ>& m, P<double> D, P<TQ> S, P<TQ> A, P<
       // (+ the adjoint in fp32) per interior-point iteration, rollout + adjoint of the interior start, the final rollout
     const int wp = wpasses % 1000;
     // (bit 15: the float interior point broke down and the double one ran from the start -- its iterations are counted too)
-    *work = (it + passes + wp) | (broke ? 0x8000 : 0) | ((wp + passes + 3 * it + 2 + (need_roll ? 1 : 0) + (broke ? 2 : 0)) << 16);
+    const unsigned sweeps = (unsigned)(wp + passes + 3 * it + 2 + (need_roll ? 1 : 0) + (broke ? 2 : 0));
+    *work = (int)((unsigned)(it + passes + wp) | (broke ? 0x8000u : 0u) | ((sweeps < 2047u ? sweeps : 2047u) << 16) | ((unsigned)(fit < 31 ? fit : 31) << 27));
   }
   return it + passes + wpasses + (m.flip_max >= 0 && chg > m.flip_max ? 10000 : 0) + 100000 * why;
 }

@@ -148,7 +148,13 @@ class Engine:
         """(factorisations, vector sweeps) the last solve of every quadrotor executed."""
         out = np.zeros(self.B, np.int32)
         self._check(self.lib.mpcq_get_qp_work(self.h, _lib.i(out)))
-        return out & 0x7FFF, out >> 16
+        return out & 0x7FFF, (out >> 16) & 0x7FF
+
+    def get_qp_float_iterations(self):
+        """fp64 instances: how many interior-point iterations of the last solve ran in float (bits 27..31 of mpcq_get_qp_work)."""
+        out = np.zeros(self.B, np.int32)
+        self._check(self.lib.mpcq_get_qp_work(self.h, _lib.i(out)))
+        return (out.view(np.uint32) >> 27).astype(np.int32)
 
     def get_qp_float_breakdown(self):
         """fp64 instances: True where the float interior point of the last (fallback) solve broke down and the double one ran instead."""

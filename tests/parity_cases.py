@@ -90,6 +90,52 @@ def case_tumbling_window(make_engine, precision, first=100, last=130):
     return worst, clean, flagged, worst_flagged
 
 
+def case_f32_every_solve_against_f64(make_engine, B, N, nb, K, seed, preroll=0, dump_prefix=None):
+    """EVERY solve of an f32 (mixed-precision) lockstep run of the bench workload against the fp64 engine on the same inputs: before each
+    period the fp64 engine's state (iterate, RGP state, cursors, plant state) is overwritten with the f32 engine's, both take the period, the
+    controls are compared per quadrotor -- relative to the quadrotor's OWN largest control (floor 1e-2: an idling quadrotor is not judged
+    against full thrust).  The fp64 engine matches the CPU oracle to 1e-10 on this workload (test_bench_workload_parity_vs_oracle), so this is
+    the oracle check at a sample size the oracle cannot reach (10^5 .. 10^6 solves).  Returns a dict: solves / worst deviation / solves beyond
+    1e-4 by reported status, and the list of flagged or out-of-budget solves."""
+    import bench
+    from mpc_quad_ros_amd.engine import qp_fallback
+    refs = bench.workload(seed, 0, B, preroll + K + 10)
+    mk = lambda prec: make_engine(EngineConfig(batch=B, N=N, T=1.0, quad=hummingbird(), nb=nb, basis=rgp_basis_linspace(12.0, nb), theta=[1.0, 0.1, 0.1],
+                                               dt_pred=0.01, precision=prec))
+    e32, e64 = mk(1), mk(0)
+    for e in (e32, e64):
+        e.set_trajectories(*refs); e.sim_reset(np.tile(bench.X0, (B, 1)))
+    if preroll:
+        e32.sim_run(preroll, 2, 5e-3)
+    out = {key: dict(solves=0, worst=0.0, beyond=0) for key in ("clean", "flagged", "failed")}
+    out.update(fallback_clean_worst=0.0, hits=[], B=B, N=N, nb=nb, seed=seed, periods=K, preroll=preroll)
+    saved = 0
+    for k in range(K):
+        st, prev_it = e32.get_state(), e32.get_qp_iter()
+        x = e32.sim_get_state()[0]
+        e64.set_state(**st); e64.sim_reset(x)
+        e32.sim_steps(1, 2, 5e-3); e64.sim_steps(1, 2, 5e-3)
+        w32, w64 = e32.sim_get_state()[1], e64.sim_get_state()[1]
+        s32, s64, it = e32.get_status(), e64.get_status(), e32.get_qp_iter()
+        assert (s64 == 0).all(), (k, np.flatnonzero(s64))
+        dev = np.abs(w32 - w64).max(axis=1) / np.maximum(np.abs(w64).max(axis=1), 1e-2)
+        for key, sel in (("clean", s32 == 0), ("flagged", s32 == 8), ("failed", (s32 & 7) != 0)):
+            if sel.any():
+                o = out[key]
+                o["solves"] += int(sel.sum()); o["worst"] = max(o["worst"], float(dev[sel].max())); o["beyond"] += int((dev[sel] > 1e-4).sum())
+        fb = qp_fallback(it) & (s32 == 0)
+        if fb.any():
+            out["fallback_clean_worst"] = max(out["fallback_clean_worst"], float(dev[fb].max()))
+        for b in np.flatnonzero((s32 != 0) | (dev > 1e-4)):
+            out["hits"].append((preroll + k, int(b), int(s32[b]), int(it[b]), float(dev[b]), float(np.abs(w32[b] - w64[b]).max()), float(np.abs(w64[b]).max())))
+            if dump_prefix and saved < 4:      # the state in front of the solve, for a single-quadrotor replay on the lane emulator
+                np.savez(f"{dump_prefix}_{saved}.npz", N=N, nb=nb, k=preroll + k, b=b, x=x[b], traj=refs[0][b], len=refs[1][b], prev=prev_it[b], w32=w32[b], w64=w64[b],
+                         **{f"st_{name}": v[b] for name, v in st.items()})
+                saved += 1
+    e32.close(); e64.close()
+    return out
+
+
 def case_free_running_log(make_engine, name, K, precision=0):
     """P2: engine and oracle run independently from the cold start on a contractive window."""
     g = load_golden(name)

