@@ -478,9 +478,9 @@ def test_bf16_record_storage_misses_the_budget():
     x = np.tile(np.array([0, 0, 3.0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]), (B, 1))
     dev = {k: [] for k in engines}
     for k in range(K):
+        for e in engines.values():
+            e.set_state(**o.get_state())      # teacher-forced: the oracle's state BEFORE its step (every solve judged on its own)
         wo, _ = o.step(x)
-        for name, e in engines.items():
-            e.set_state(**o.get_state()) if k else None      # teacher-forced from the second period on (every solve judged on its own)
         for name, e in engines.items():
             w, _ = e.step(x)
             assert ((e.get_status() & 7) == 0).all(), (name, k)
