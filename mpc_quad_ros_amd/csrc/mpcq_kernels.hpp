@@ -2301,6 +2301,13 @@ MPCQ_PHASE void adjoint64_bwd(const DevModel<float>& m, P<double> D, P<float> S,
 // left is that times the contraction, a few per cent), or when the residual says the previous one already was.  Multiplier signs are
 // judged on the double values.  A warm solve without a change of the working set costs one factorisation and three sweeps.
 // On success D[L.zd], D[L.dxd] hold the solution, S[L.z] its float image.
+// Mixed precision, a working set that cycles at the most careful release level (the sign test has been loosened once already): the classical
+// primal rule from there on -- a Newton step that leaves the box is taken up to the FIRST bound it meets and only that input is pinned
+// (instead of clipping and pinning every violator at once, which is what makes the float method cycle when its Newton steps are too
+// inaccurate to tell which of two nearly tied inputs blocks first).  0: off (round 5 behaviour).
+#ifndef MPCQ_MIXED_ONEPIN
+#define MPCQ_MIXED_ONEPIN 1
+#endif
 #ifndef MPCQ_MIXED_TOLC
 #define MPCQ_MIXED_TOLC 1e-6   // (1e-5 until round 6: see the weak-multiplier note in polish_mixed; 1e-6 costs nothing measurable)
 #endif
@@ -2347,6 +2354,7 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
   //   3  the worst one overall (the classical rule).
   // The level rises when a release bounces (the freed inputs get pinned again) and when its Newton step is wild (below).  Thresholds and
   // candidates both come from the float images of the multipliers in S[L.grad], so the worst one always passes its own threshold.
+  int rel_idx = -1;
   auto release = [&](const int level) {
     float vr = 0;
     for (int i = tid; i < nv; i += 64) {
@@ -2362,11 +2370,13 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
       if (level == 2) rel_thr = tmax(rel_thr, 0.625f * vall);
     }
     const float weak = level == 1 ? 1e-4f * gm : 0.0f;
+    int ri = -1;
     for (int i = tid; i < nv; i += 64) {
       const TQ a = S[L.act + i], g = S[L.grad + GI(i)];
       const float v = a < 0 ? -g : g;
-      if (a != TQ(0) && (double)v > tolm && (v >= rel_thr || v <= weak)) S[L.act + i] = 0;
+      if (a != TQ(0) && (double)v > tolm && (v >= rel_thr || v <= weak)) { S[L.act + i] = 0; ri = i; }
     }
+    rel_idx = level == 3 ? wave_max(ri) : -1;   // (level 3 releases one input: the one a single-pin step may meet again)
   };
   // max_passes budgets FACTORISATIONS (as in the fp64 method, where a pass is one): a refinement step reuses the factorisation at hand and is
   // not charged -- a warm solve without a change of the working set is two trips of this loop and one factorisation.  (Charging trips made
@@ -2485,7 +2495,32 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
     viol = wave_reduce(viol, [](int a, int b) { return a | b; });
     if (viol & 2) { why = QPX_NUMERIC; return false; }
     dzm = wave_max(dzm);
-    int nblk = 0;
+    int nblk = 0, pin_idx = -1;
+    double alpha_pin = 1.0;
+    const bool onepin = MPCQ_MIXED_ONEPIN != 0 && !aff && careful >= 3 && loosened > 0 && viol != 0;
+    if (onepin) {   // (see MPCQ_MIXED_ONEPIN) up to the first bound the step meets; that input alone joins the working set
+      double amin = 2.0;
+      int imin = nv;
+      for (int i = tid; i < nv; i += 64) {
+        if (S[L.act + i] != TQ(0)) continue;
+        const double z = D[L.zd + i], d = (double)S[L.dz + i], zn = z + d, lb = lbd(i), ub = ubd(i);
+        double a = 2.0;
+        if (zn < lb) a = (lb - z) / d; else if (zn > ub) a = (ub - z) / d;
+        a = a < 0.0 ? 0.0 : a;
+        if (a < amin) { amin = a; imin = i; }
+      }
+      alpha_pin = wave_min(amin);
+      pin_idx = wave_min(amin == alpha_pin ? imin : nv);
+      for (int i = tid; i < nv; i += 64) {
+        if (S[L.act + i] != TQ(0)) continue;
+        const double lb = lbd(i), ub = ubd(i), d = (double)S[L.dz + i];
+        double z = D[L.zd + i] + alpha_pin * d;
+        z = z < lb ? lb : (z > ub ? ub : z);
+        if (i == pin_idx) { z = d < 0.0 ? lb : ub; S[L.act + i] = d < 0.0 ? TQ(-1) : TQ(1); }
+        D[L.zd + i] = z;
+      }
+      nblk = 1;
+    } else {
     for (int i = tid; i < nv; i += 64) {
       if (S[L.act + i] != TQ(0)) continue;
       const double lb = lbd(i), ub = ubd(i);
@@ -2497,6 +2532,7 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
       D[L.zd + i] = z;
     }
     nblk = wave_sum(nblk);
+    }
 #ifdef MPCQ_EMU_DEBUG
     if (tid == 0) printf("     step %.3e nblk %d corrected %d\n", dzm, nblk, (int)corrected);
 #endif
@@ -2510,8 +2546,10 @@ MPCQ_PHASE bool polish_mixed(const DevModel<float>& m, P<double> D, P<float> S, 
         // pinned again by a step that leaves the box by a rounding error -- the input is degenerate (it sits on its bound with a multiplier
         // of zero to rounding): the sign test is loosened until the pair stops trading places (seen on the bench workload's own seed: one
         // input released and re-pinned sixty times until the budget was gone)
+        // (single-pin steps: a release followed by a pin is the method at work, not a bounce -- unless the step pins the input just
+        //  released without having moved: that one is degenerate)
         if (careful < 3) careful += 1;
-        else { tolm *= 100.0; loosened += 1; }
+        else if (!onepin || (pin_idx == rel_idx && alpha_pin < 1e-9)) { tolm *= 100.0; loosened += 1; }
       }
     }
     released = false;

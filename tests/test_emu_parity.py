@@ -252,11 +252,12 @@ def test_emu_f32_saturating_references_through_the_interior_point():
 
 def test_emu_tumbling_flight_is_solved_or_flagged():
     """The f32 validity limit at its edge (tests/test_gpu_parity.py runs periods 100 .. 129 in both precisions): periods 112 .. 121 of the reference's
-    tumbling traj2_v10_a10_gp2 flight on the emulator -- two of them (116, 120) the float factorisation cannot refine: flagged, not returned
-    as clean solves; everything with status 0 within the budget."""
+    tumbling traj2_v10_a10_gp2 flight on the emulator.  Two of them (116, 120) make the working set cycle under the float factorisation: round 5
+    returned them 0.13 / 0.43 of full thrust off with status 0; flagged in the first half of round 6; solved since the method falls back to
+    single-pin steps once it cycles (MPCQ_MIXED_ONEPIN).  Every solve: status 0 within the budget, or flagged."""
     worst, clean, flagged, worst_flagged = pc.case_tumbling_window(make, 1, first=112, last=122)
     print("emu tumbling window f32:", worst, clean, flagged, worst_flagged)
-    assert clean >= 7 and flagged >= 1 and worst_flagged > 1e-2
+    assert clean + flagged == 10 and clean >= 9
     worst, clean, flagged, _ = pc.case_tumbling_window(make, 0, first=114, last=121)
     assert flagged == 0 and worst < 1e-8
 
