@@ -547,7 +547,8 @@ def main():
         elapsed = float(t[0])
     # every rank's own clock around its K launches (the barrier that ends the region is included in `elapsed`, not here)
     ranks = per_rank_summary(dist, world, {"ms_per_step": 1e3 * own_elapsed / args.steps, "kernel_avg_ms": 1e3 * k_avg_own,
-                                           "steps_per_s": B * args.steps / own_elapsed})
+                                           "steps_per_s": B * args.steps / own_elapsed,
+                                           "host_generation_s": t_gen})      # every rank generates its own references concurrently (round-5 verdict, item 9)
     stats, stats_reduce2, hung2 = reduce_stats(e, dist, world, stats_reduce == "rccl")
     if world > 1:
         stats_reduce, rccl_hung = (stats_reduce2 if stats_reduce == "rccl" else stats_reduce), rccl_hung or hung2

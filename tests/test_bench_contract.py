@@ -108,6 +108,9 @@ def test_eight_ranks_reduce_both_statistics_through_the_rccl_branch():
     pr = d["per_rank"]
     assert len(pr["ranks"]) == 8
     assert abs(d["efficiency_vs_best_rank"] - d["value"] / (8 * pr["steps_per_s"]["max"])) < 1e-12 and 0 < d["efficiency_vs_best_rank"] <= 1.0 + 1e-9
+    # every rank reports how long its host-side generation of the references took under 8 concurrent ranks (round-5 verdict, item 9): the
+    # driver's budget is minutes; here (tiny shapes, eight processes on the CPUs of this container) seconds
+    assert all(0 <= r["host_generation_s"] < 120 for r in pr["ranks"])
     # the swarm leg: 2 quadrotors on each of 8 ranks, its statistic over the same communicator
     sw = d["swarm"]
     assert sw["n_gpus"] == 8 and sw["global_batch"] == 16 and sw["stats_reduce"] == "rccl"
