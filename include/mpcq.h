@@ -109,7 +109,8 @@ typedef struct mpcq_tuning {
                            1..16; 0 automatic: 1 for a batch that is resident on the device as a whole, 2 for a larger one (the tail of one
                            group's launch -- the device draining while the last workgroups finish -- is filled by the other group's next
                            launch).  A call still ends with EVERY quadrotor K periods on and quadrotors are independent: results do not
-                           depend on it.  mpcq_step / mpcq_step_device_async (one period per call) are always one launch over the batch. */
+                           depend on it.  mpcq_step / mpcq_step_device_async (one period per call) are always one launch over the batch.
+                           More than four groups oversubscribe the hardware queues of the device and are slower. */
 } mpcq_tuning;
 
 /* Engine configuration.  Replaces the constructor arguments of quad_optimizer

@@ -1,3 +1,4 @@
+"""Diagnostic (GPU box): which layout and residency the engine picks at B = 8192 (MPCQ_VERBOSE line); MPCQ_LIB names the build (tools/r6_ab.sh variants)."""
 import os, sys
 os.environ["MPCQ_TUNING"]="1"; os.environ["MPCQ_VERBOSE"]="1"
 sys.path.insert(0,'.')
