@@ -48,10 +48,10 @@ typedef enum mpcq_status {
                                      Either the refinement of the QP solution against fp64 residuals did not converge (the step is the
                                      interior point's float answer), or the working set cycled under the float factorisation and the set the
                                      method settled on ignores a wrong-signed multiplier worth more than 1e-6 of a control (round 6; until then
-                                     such solves came back with status 0, up to 0.43 of full thrust off on a flight that tumbles).  Not seen
-                                     on the bench workload since the method takes single-pin steps once it cycles (3.35 M solves checked
-                                     against the fp64 engine; INTEGRATION.md says the same); expected where a flight is
-                                     lost altogether (predictions with a cost of 1e10 and more).  Every solve that reports 0 is within the
+                                     such solves came back with status 0, up to 0.43 of full thrust off on a flight that tumbles).  One in 7 M
+                                     solves of the bench workload checked against the fp64 engine, on a quadrotor that is lost (QP gradient
+                                     scale 1e9; DESIGN.md section 3.2, INTEGRATION.md says the same): expected where a flight is lost
+                                     altogether.  Every solve that reports 0 is within the
                                      budget (tests/parity_cases.py: case_f32_every_solve_against_f64).  Not a failure:
                                      mpcq_get_tracking_stats out[4] does not count it */
 
@@ -71,8 +71,8 @@ typedef enum mpcq_status {
  * of the QP evaluated in double on those records, the float factorisation solving for the corrections (iterative refinement).
  * Holds the north_star budget on every solve it reports with status 0 -- warm, cold start, interior-point fallback, saturated inputs:
  * <= 1e-4 relative control deviation from the fp64 oracle, teacher-forced (tests/test_gpu_parity.py; observed <= 2.4e-5, median
- * 2e-8 .. 4e-7).  Status 0 is what every solve of the tests and of 3.35 M audited solves of the bench workload reports; a solve the float
- * factorisation cannot refine says so (see MPCQ_SOLVE_LOW_ACCURACY). */
+ * 2e-8 .. 4e-7).  Status 0 is what every solve of the tests reports and all but two of 7 M audited solves of the bench workload (quadrotors
+ * that are lost: flagged / MPCQ_SOLVE_NAN); a solve the float factorisation cannot refine says so (see MPCQ_SOLVE_LOW_ACCURACY). */
 #define MPCQ_PRECISION_F64 0
 #define MPCQ_PRECISION_F32 1
 
