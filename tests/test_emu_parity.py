@@ -296,3 +296,13 @@ def test_emu_facade_mirrors_quad_optimizer(lib=EMU):
     o.rgp_regress(vb, ad); mu_o, C_o = o.get_rgp()
     assert len(mu) == 3 and mu[0].shape == (B, nb) and C[0].shape == (B, nb, nb)
     assert np.abs(np.stack(mu, 1) - mu_o).max() < 1e-12 and np.abs(np.stack(C, 1) - C_o).max() < 1e-12
+
+
+def test_emu_lost_quadrotors_are_solved_in_fp64_and_flagged_in_f32():
+    """tests/golden/f32_lost_quadrotors.npz on the lane emulator (the GPU test of the same name): the float arithmetic of the emulator breaks
+    down on the same two quadrotors (status 1 and 8 where the MI355X reports 8 and 1) and solves the idling one."""
+    rows = pc.case_lost_quadrotors(make)
+    for row in rows:
+        print("%s: fp64 status %d deviation %.1e | f32 status %d deviation %.1e" % row)
+    assert [r[1] for r in rows] == [0, 0, 0]
+

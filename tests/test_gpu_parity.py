@@ -43,6 +43,13 @@ def test_tumbling_flight_of_the_reference_is_solved_or_flagged(precision):
         assert clean >= 25 and clean + flagged == 30      # (emulator: 29 clean, one flagged with the answer right)
 
 
+def test_lost_quadrotors_of_the_bench_workload_are_solved_in_fp64_and_flagged_in_f32():
+    """The solves the widened f32 audit found (two lost quadrotors, one idling one): fp64 status 0 and the oracle's control; f32 accurate or
+    flagged / failed, never silently wrong (on the MI355X: status 8, status 0 at 1.3e-6 of full thrust, status 1)."""
+    for row in pc.case_lost_quadrotors(make):
+        print("%s: fp64 status %d deviation %.1e | f32 status %d deviation %.1e" % row)
+
+
 @pytest.mark.parametrize("name,K", [("log_traj1_v10_a10_gp0.npz", 200), ("log_traj0_v10_a10_gp2.npz", 110),
                                     ("log_traj0_v15_a5_gp2.npz", 150)])
 def test_free_running_on_contractive_windows(name, K):
